@@ -1,0 +1,140 @@
+"""Oracle: third-party arithmetic the path depends on.
+
+* glibc 2.35 expf/logf (what Rust f32::exp / f32::ln call; mcts.rs:379,430,451-453): the
+  restatement is swept against the HOST libm.  The default run strides the sweep; `-m slow`
+  runs every bit pattern.
+* rand 0.10.1 / chacha20 0.10.1 / rand_core 0.10.1 (Cargo.lock:1585-1593,269-277,1621-1622;
+  call site mcts.rs:214-222): ChaCha block pinned by published vectors; the rest restated
+  from the crates' documented algorithm -- PARITY UNPINNED against the real crates.
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import c4oracle as O
+
+
+def _sweep(fn, lo, hi, stride):
+    bad = C.c_uint32(0)
+    n = fn(lo, hi, stride, C.byref(bad))
+    return n, bad.value
+
+
+def test_expf_strided_sweep_vs_host_libm():
+    L = O.lib()
+    # negative inputs down to -inf/NaN range, positive up to +inf/NaN range
+    for lo, hi in [(0x80000000, 0xFFFFFFFF), (0x00000000, 0x7FFFFFFF)]:
+        n, bad = _sweep(L.c4o_sweep_expf, lo, hi, 977)
+        assert n == 0, hex(bad)
+    # the two inputs where only the fused r = fma(InvLn2N, x, -kd) matches
+    for x in (-float.fromhex("0x1.f8cbb2p+5"), float.fromhex("0x1.04845ep+5")):
+        xi = struct.unpack("<I", struct.pack("<f", x))[0]
+        assert _sweep(L.c4o_sweep_expf, xi, xi, 1)[0] == 0
+
+
+def test_expf_dense_window_vs_host_libm():
+    # softmax arguments live in [-30, 0]: sweep that window densely
+    L = O.lib()
+    lo = struct.unpack("<I", struct.pack("<f", -0.0))[0]
+    hi = struct.unpack("<I", struct.pack("<f", -30.0))[0]
+    n, bad = _sweep(L.c4o_sweep_expf, lo, hi, 13)
+    assert n == 0, hex(bad)
+
+
+def test_logf_strided_sweep_vs_host_libm():
+    L = O.lib()
+    n, bad = _sweep(L.c4o_sweep_logf, 0x00000000, 0xFFFFFFFF, 977)
+    assert n == 0, hex(bad)
+    # integer arguments (ln of visit counts, mcts.rs:379) and probabilities k/n
+    xs = np.arange(0, 200001, dtype=np.float32)
+    ys = np.empty_like(xs)
+    L.c4o_host_logf(xs.ctypes.data_as(C.POINTER(C.c_float)), ys.ctypes.data_as(C.POINTER(C.c_float)), xs.size)
+    mine = np.array([L.c4o_logf(float(x)) for x in xs[:5000]], dtype=np.float32)
+    assert np.array_equal(mine.view(np.uint32), ys[:5000].view(np.uint32))
+
+
+@pytest.mark.slow
+def test_expf_logf_exhaustive_vs_host_libm():
+    L = O.lib()
+    assert _sweep(L.c4o_sweep_expf, 0, 0xFFFFFFFF, 1)[0] == 0
+    assert _sweep(L.c4o_sweep_logf, 0, 0xFFFFFFFF, 1)[0] == 0
+
+
+def test_special_values():
+    L = O.lib()
+    assert L.c4o_expf(float("-inf")) == 0.0 and L.c4o_expf(0.0) == 1.0
+    assert L.c4o_logf(0.0) == float("-inf") and L.c4o_logf(1.0) == 0.0
+    assert np.isnan(L.c4o_logf(-1.0)) and np.isnan(L.c4o_expf(float("nan")))
+
+
+# ---- RNG -------------------------------------------------------------------------------------
+def _words_to_bytes(ws):
+    return b"".join(struct.pack("<I", w) for w in ws)
+
+
+def test_chacha20_rfc7539_zero_key_block():
+    # RFC 7539 section 2.3.2-style all-zero key/nonce/counter keystream block
+    blk = O.chacha_block(bytes(32), 0, 20)
+    assert _words_to_bytes(blk)[:16].hex() == "76b8e0ada0f13d90405d6ae55386bd28"
+    assert _words_to_bytes(blk).hex() == (
+        "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"
+        "da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+
+
+def test_chacha12_estream_zero_key_block():
+    blk = O.chacha_block(bytes(32), 0, 12)
+    assert _words_to_bytes(blk)[:32].hex() == "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f"
+
+
+def test_chacha_counter_is_words_12_13():
+    a = O.chacha_block(bytes(32), 1, 20)
+    # RFC 7539 Appendix A.1 test vector #2: zero key, block counter 1
+    assert _words_to_bytes(a)[:16].hex() == "9f07e7be5551387a98ba977c732d080d"
+
+
+SEED_TABLE = [  # SURVEY Appendix A.1 (independent scratch restatement): seed -> key, first u32, u01
+    (0, "ecf273f981b5cd4587f0467306ad6cadd0d0a3e33317e767f29bea72d78a7dfe", 0xCD2C6F7F, 0.8014591932296753),
+    (1, "ead81d725d26104e899c3bf842ce782ebad303da9997d2c2120256ac7366fb1b", 0xD3301861, 0.8249526023864746),
+    (42, "a48fa17b58323d0aeab8a1cc690114b82b8cc87518b4f7548d446ea1e4df20f2", 0x222724A2, 0.13340973854064941),
+    (43, "229d6fa798b1d804d9b7592c388dcfd97283da0efd1677faf49aa9925a051bb3", 0xEC8A28F6, 0.923983097076416),
+    (86, "f2e4cf3b78b70c603ba6adfa48db318b943946f9b794b57548ec3cc81eecb70c", 0xF57683D2, 0.9588395357131958),
+]
+
+
+def test_seed_expansion_and_first_word_regression():
+    L = O.lib()
+    for seed, key_hex, first, u01 in SEED_TABLE:
+        assert O.seed_key(seed).hex() == key_hex
+        assert L.c4o_rng_first_u32(seed) == first
+        got = np.frombuffer(struct.pack("<I", 0x3F800000 | (first >> 9)), dtype=np.float32)[0] - np.float32(1.0)
+        assert float(got) == u01
+
+
+def test_weighted_index_semantics():
+    # x = u01 * scale; index = #cumulative weights <= x  (partition_point)
+    w = [0.25, 0.25, 0.0, 0.25, 0.0, 0.0, 0.25]
+    assert O.weighted_index(w, 0) == 0
+    assert O.weighted_index(w, 0x40000000) == 1          # u01 = 0.25 -> cum[0] <= x -> 1
+    assert O.weighted_index(w, 0x80000000) == 3          # 0.5 -> skips the zero-weight column 2
+    assert O.weighted_index(w, 0xFFFFFFFF) == 6          # top of the range lands in the last non-zero weight
+    one_hot = [0, 0, 0, 0, 1.0, 0, 0]
+    for u in (0, 1 << 31, 0xFFFFFFFF):
+        assert O.weighted_index(one_hot, u) == 4
+    for bad in ([0.0] * 7, [0.5, -0.1, 0, 0, 0, 0, 0.6], [float("nan")] + [0.1] * 6):
+        with pytest.raises(ValueError):
+            O.weighted_index(bad, 123)
+
+
+def test_sample_move_seed_formula():
+    # mcts.rs:215 seed = game_id * (42 + n_moves): game 0 always seeds 0; 43*42 == 42*43 collide
+    p = [1 / 7] * 7
+    assert O.sample_move(0, 0, p, 1.0) == O.sample_move(0, 5, p, 1.0)
+    assert O.sample_move(43, 0, p, 1.0) == O.sample_move(42, 1, p, 1.0)
+    cols = {O.sample_move(g, 0, p, 4.0) for g in range(200)}
+    assert cols == set(range(7))
+    # zero-probability moves are never sampled, at any temperature
+    q = [0.0, 0.5, 0.0, 0.5, 0.0, 0.0, 0.0]
+    for g in range(300):
+        assert O.sample_move(g, 3, q, 2.0) in (1, 3)
