@@ -1,0 +1,103 @@
+"""ctypes binding of libc4a0_hip.so (the C ABI declared in include/c4a0_hip.h).
+
+The library is the product: there is no CPU fallback.  If it is missing, `lib()` raises with
+the build command instead of degrading to something else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libc4a0_hip.so")
+
+OK, ERR_BAD_ARG, ERR_HIP, ERR_NAN_IN_TREE, ERR_DEGENERATE_POLICY, ERR_ARENA_OVERFLOW, ERR_NOT_BOUND, ERR_NO_DEVICE, ERR_ILLEGAL_MOVE = range(9)
+STATUS_NAMES = {
+    0: "C4_OK", 1: "C4_ERR_BAD_ARG", 2: "C4_ERR_HIP", 3: "C4_ERR_NAN_IN_TREE", 4: "C4_ERR_DEGENERATE_POLICY",
+    5: "C4_ERR_ARENA_OVERFLOW", 6: "C4_ERR_NOT_BOUND", 7: "C4_ERR_NO_DEVICE", 8: "C4_ERR_ILLEGAL_MOVE",
+}
+FLAG_NO_MOVES = 1
+MAX_SAMPLES_PER_GAME = 43
+
+
+class C4Error(RuntimeError):
+    def __init__(self, status: int, detail: str = ""):
+        self.status = status
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {detail}" if detail else STATUS_NAMES.get(status, str(status)))
+
+
+class GameMetadataC(C.Structure):
+    _fields_ = [("game_id", C.c_uint64), ("player0_id", C.c_uint64), ("player1_id", C.c_uint64)]
+
+
+class SampleRec(C.Structure):
+    _fields_ = [("game_id", C.c_uint64), ("mask", C.c_uint64), ("value", C.c_uint64), ("policy", C.c_float * 7),
+                ("q_penalty", C.c_float), ("q_no_penalty", C.c_float), ("meta", C.c_uint32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("n_slots", C.c_uint32), ("blocks_per_slot", C.c_uint32), ("n_mcts_iterations", C.c_uint32),
+                ("c_exploration", C.c_float), ("c_ply_penalty", C.c_float), ("planes_dtype", C.c_uint32),
+                ("flags", C.c_uint32), ("device", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("sims", "select_levels", "backup_nodes", "expansions", "moves", "games_done",
+                                          "ref_skipped_sims", "samples", "games_started")] + \
+               [("error", C.c_uint32), ("error_slot", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+# every symbol include/c4a0_hip.h declares: name -> (restype, argtypes)
+_P = C.POINTER
+_vp = C.c_void_p
+SIGNATURES = {
+    "c4_last_error_string": (C.c_char_p, []),
+    "c4_device_count": (C.c_int, [_P(C.c_int)]),
+    "c4_session_create": (C.c_int, [_P(Config), _P(_vp)]),
+    "c4_session_destroy": (C.c_int, [_vp]),
+    "c4_session_set_games": (C.c_int, [_vp, _P(GameMetadataC), C.c_uint64, _P(C.c_uint64), _P(C.c_uint64)]),
+    "c4_session_bind_io": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "c4_session_start": (C.c_int, [_vp]),
+    "c4_session_step": (C.c_int, [_vp]),
+    "c4_session_counters": (C.c_int, [_vp, _P(Counters)]),
+    "c4_session_poll": (C.c_int, [_vp, _P(C.c_uint64), _P(C.c_uint32)]),
+    "c4_session_sample_counts": (C.c_int, [_vp, _P(C.c_uint32), C.c_uint64]),
+    "c4_session_drain_samples": (C.c_int, [_vp, _P(SampleRec), C.c_uint64, _P(C.c_uint64)]),
+    "c4_session_sample_store": (C.c_int, [_vp, _P(_vp), _P(_vp), _P(C.c_uint64)]),
+    "c4_session_root_stats": (C.c_int, [_vp, C.c_uint32, _P(C.c_float), _P(C.c_float), _P(C.c_float),
+                                        _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint64)]),
+    "c4_session_leaves": (C.c_int, [_vp, _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint32), _P(C.c_uint32)]),
+    "c4_pos_ops": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "c4_encode_planes": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp]),
+    "c4_expf_logf": (C.c_int, [_vp, C.c_uint64, C.c_int, _vp, _vp]),
+    "c4_softmax7": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "c4_apply_temperature": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "c4_sample_move": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension is the product and there is no fallback. "
+                "Build it with `python c4a0_amd/csrc/build.py` (hipcc --offload-arch=gfx950).")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != OK:
+        msg = lib().c4_last_error_string()
+        raise C4Error(status, msg.decode() if msg else "")

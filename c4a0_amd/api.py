@@ -1,0 +1,132 @@
+"""`play_games` -- the drop-in entry point (reference rust/src/pybridge.rs:20-53,
+src/c4a0_rust/__init__.pyi:49-56).
+
+Same six positional arguments as the reference.  Two evaluator modes:
+
+* callback mode (reference-compatible): `py_eval_pos_cb(model_id, float32[B,2,6,7]) ->
+  (float32[B,7], float32[B], float32[B])`, B <= max_nn_batch_size, unique positions per call,
+  never called concurrently (pybridge.rs:161-199, self_play.rs:196-237).  Costs a host round
+  trip per step -- exactly what the reference does -- while the tree work stays on the GPU.
+* device mode (keyword `evaluator=`): a callable on device tensors, `evaluator(planes[G,2,6,7])
+  -> (logprobs[G,7], q[G,2])`, e.g. `c4a0_amd.nn.InferenceNet`; leaf batches never leave HBM.
+
+The tree path always runs in the HIP kernels; there is no CPU implementation to fall back to.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .results import GameMetadata, PlayGamesResult, results_from_records
+from .session import DeviceEvaluator, DeviceSession
+
+DEFAULT_RESIDENT_GAMES = 16384
+
+
+def _planes_from_bits(mask: np.ndarray, value: np.ndarray) -> np.ndarray:
+    """create_pos_batch (pybridge.rs:202-221) for arrays of positions -> float32[B,2,6,7]."""
+    bits = np.arange(42, dtype=np.uint64)[None, :]
+    p0 = ((value[:, None] >> bits) & np.uint64(1)).astype(np.float32)
+    p1 = (((mask & ~value)[:, None] >> bits) & np.uint64(1)).astype(np.float32)
+    return np.concatenate([p0, p1], axis=1).reshape(-1, 2, 6, 7)
+
+
+class _CallbackEvaluator:
+    """PyEvalPos (pybridge.rs:161-199) + the batching semantics of NNThread::loop_once
+    (self_play.rs:196-237): per step, the unique (model, leaf position) pairs of all resident
+    games are evaluated in chunks of at most max_nn_batch_size, one model per call."""
+
+    def __init__(self, session: DeviceSession, cb: Callable, max_nn_batch_size: int, slot_models):
+        self.s, self.cb, self.cap = session, cb, max(1, int(max_nn_batch_size))
+        self.slot_models = slot_models  # callable(ordinals) -> (player0_ids, player1_ids)
+        g = session.n_slots
+        self.lp = np.zeros((g, 7), dtype=np.float32)
+        self.q = np.zeros((g, 2), dtype=np.float32)
+        self.nn_positions = 0
+
+    def __call__(self, _planes: torch.Tensor):
+        mask, value, status, ordinal = self.s.leaves(with_ordinals=True)
+        act = np.nonzero(status == 1)[0]
+        if act.size:
+            p0, p1 = self.slot_models(ordinal[act])
+            ply = np.array([bin(int(m)).count("1") for m in mask[act]], dtype=np.int64)
+            model = np.where(ply % 2 == 0, p0, p1)  # mcts.rs:70-76
+            keys = np.stack([model.astype(np.uint64), mask[act], value[act]], axis=1)
+            uniq, inv = np.unique(keys, axis=0, return_inverse=True)
+            inv = inv.reshape(-1)
+            ulp = np.zeros((uniq.shape[0], 7), dtype=np.float32)
+            uq = np.zeros((uniq.shape[0], 2), dtype=np.float32)
+            for mid in np.unique(uniq[:, 0]):
+                rows = np.nonzero(uniq[:, 0] == mid)[0]
+                for i in range(0, rows.size, self.cap):
+                    r = rows[i:i + self.cap]
+                    batch = _planes_from_bits(uniq[r, 1], uniq[r, 2])
+                    out = self.cb(int(mid), batch)
+                    if not (isinstance(out, (tuple, list)) and len(out) == 3):
+                        raise TypeError("py_eval_pos_cb must return (policy_logprobs, q_penalty, q_no_penalty)")
+                    lp, qp, qn = (np.asarray(a) for a in out)
+                    for name, a, shape in (("policy", lp, (r.size, 7)), ("q_penalty", qp, (r.size,)), ("q_no_penalty", qn, (r.size,))):
+                        # pybridge.rs:175-188: contiguous float32 arrays of the batch's shape
+                        if a.dtype != np.float32 or a.shape != shape or not a.flags["C_CONTIGUOUS"]:
+                            raise TypeError(f"py_eval_pos_cb: {name} must be C-contiguous float32 of shape {shape}, got {a.dtype} {a.shape}")
+                    ulp[r], uq[r, 0], uq[r, 1] = lp, qp, qn
+                    self.nn_positions += r.size
+            self.lp[act], self.q[act] = ulp[inv], uq[inv]
+        dev = self.s.device
+        self.s.logprobs.copy_(torch.from_numpy(self.lp).to(dev, non_blocking=False))
+        self.s.q.copy_(torch.from_numpy(self.q).to(dev, non_blocking=False))
+        return self.s.logprobs, self.s.q
+
+
+def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iterations: int,
+               c_exploration: float, c_ply_penalty: float, py_eval_pos_cb: Optional[Callable] = None, *,
+               evaluator: Optional[DeviceEvaluator] = None, device=None, resident_games: Optional[int] = None,
+               planes_dtype: Optional[torch.dtype] = None, blocks_per_slot: int = 0,
+               stats: Optional[dict] = None) -> PlayGamesResult:
+    """Play every game of `reqs` to the end with MCTS self-play on the GPU and return the
+    training samples (reference pybridge.rs:20-53).  Results are in `reqs` order (the
+    reference's order is thread-finishing order, self_play.rs:116)."""
+    reqs = list(reqs)
+    for r in reqs:
+        if not all(hasattr(r, a) for a in ("game_id", "player0_id", "player1_id")):
+            raise TypeError("reqs must be a sequence of GameMetadata")  # reference: extract() fails, pybridge.rs:30
+    if (py_eval_pos_cb is None) == (evaluator is None):
+        raise TypeError("pass exactly one of py_eval_pos_cb (numpy callback) or evaluator= (device callable)")
+    if int(max_nn_batch_size) < 1 or int(n_mcts_iterations) < 0:
+        raise ValueError("max_nn_batch_size must be >= 1 and n_mcts_iterations >= 0")
+    if not reqs:
+        return PlayGamesResult([])
+    if evaluator is not None and any(r.player0_id != r.player1_id for r in reqs):
+        raise NotImplementedError("device-evaluator mode plays single-model games; use the callback mode for tournaments")
+
+    n_slots = min(len(reqs), int(resident_games) if resident_games else DEFAULT_RESIDENT_GAMES)
+    if planes_dtype is None:
+        planes_dtype = torch.float32
+    sess = DeviceSession(n_slots, n_mcts_iterations, c_exploration, c_ply_penalty, device=device,
+                         planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot)
+    try:
+        sess.set_games([(r.game_id, r.player0_id, r.player1_id) for r in reqs])
+        if evaluator is None:
+            p0 = np.array([r.player0_id for r in reqs], dtype=np.uint64)
+            p1 = np.array([r.player1_id for r in reqs], dtype=np.uint64)
+            ev = _CallbackEvaluator(sess, py_eval_pos_cb, max_nn_batch_size, lambda o: (p0[o], p1[o]))
+            steps = sess.run(ev, poll_every=1)
+        else:
+            ev = evaluator
+            steps = sess.run(ev)
+        counts = sess.sample_counts()
+        recs = sess.drain_samples()
+        if stats is not None:
+            stats.update(sess.counters())
+            stats["steps"] = steps
+            stats["n_slots"] = n_slots
+    finally:
+        sess.close()
+    return results_from_records([GameMetadata(r.game_id, r.player0_id, r.player1_id) for r in reqs], recs, counts)
+
+
+def run_tui(*_a, **_k):
+    """reference pybridge.rs:231-251: terminal UI -- out of scope."""
+    raise NotImplementedError("run_tui (interactive terminal UI) is out of scope of the self-play generator")

@@ -1,0 +1,874 @@
+// c4_session.hip -- GPU-resident batched MCTS self-play for Connect Four on MI355X (gfx950),
+// behind the C ABI of include/c4a0_hip.h.
+//
+// Replaces the reference's CPU loop (rust/src/self_play.rs + mcts.rs + c4r.rs): G games stay
+// resident in HBM and advance in lock-step, one MCTS simulation per game per `c4_session_step`.
+//
+// Mapping to the hardware
+//   * one game  <-> one 8-lane group of a wave64 (lanes 0..6 = the 7 children of a node,
+//     lane 7 = bookkeeping); 8 games per wavefront, one wavefront per workgroup so that a
+//     launch of G games spreads over G/8 workgroups (G = 4096 -> 512 workgroups on 256 CUs).
+//   * tree node storage = "children blocks": the 7 children of an expanded node live in ONE
+//     128-byte, 128-byte-aligned block {n, q_penalty, prior, child_block} x 7 (+ a header
+//     entry), so one select level is one cache line read by one 16-byte load per lane, and the
+//     child link needed for the next level arrives with it.  q_no_penalty (never read by
+//     selection, mcts.rs:359-361) lives in a parallel 32-byte row.
+//   * no parent links: select records the root->leaf path in the slot state and the next
+//     step's backup walks that list with independent loads (no pointer chase).
+//   * positions are not stored in nodes: select replays make_move from the root position.
+//   * arenas are bump-allocated per slot and never compacted: 288 GB of HBM holds the worst
+//     case (43 * n_mcts_iterations blocks per game) for thousands of games.
+//
+// Bit-exactness: f32 arithmetic follows the reference operation by operation; this file is
+// compiled with -ffp-contract=off (see build.py) and uses the glibc expf/logf ports.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/c4a0_hip.h"
+#include "c4_device.hpp"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// HBM layout
+// ------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) Entry {
+  uint32_t n;      // visit_count            (mcts.rs:335)
+  float q_pen;     // q_sum_penalty          (mcts.rs:336)
+  float prior;     // initial_policy_value   (mcts.rs:338)
+  uint32_t child;  // block holding this node's children, 0 = not expanded (mcts.rs:339)
+};
+struct __attribute__((aligned(128))) Block {
+  Entry e[8];  // e[0..6] = children by column; e[7] = header {legal mask, 0, 0, 0}
+};
+struct __attribute__((aligned(32))) QRow {
+  float q_nopen[8];  // q_sum_no_penalty of the 7 children (mcts.rs:337)
+};
+
+constexpr uint32_t kMaxPath = 44;
+struct __attribute__((aligned(256))) Slot {
+  uint64_t root_mask, root_value;  // MctsGame::root position
+  uint64_t leaf_mask, leaf_value;  // MctsGame::leaf position (waiting for the evaluator)
+  uint64_t game_id;
+  uint32_t ordinal;     // index into reqs / the sample store
+  uint32_t status;      // 0 idle, 1 active, >1 = c4_status error
+  uint32_t root_ref;    // (block << 3 | column) of the root's own entry
+  uint32_t root_block;  // the root's children block, 0 = root not expanded
+  uint32_t root_n;      // mirror of the root entry's visit count
+  uint32_t depth;       // leaf depth below the root; path[depth] = the leaf's entry
+  uint32_t n_blocks;    // bump pointer of this slot's arena
+  uint32_t n_moves;     // MctsGame::moves.len()
+  uint32_t pad[2];
+  uint32_t path[kMaxPath];  // entry refs root..leaf written by select, consumed by backup
+};
+static_assert(sizeof(Slot) == 256, "slot state is two cache lines");
+static_assert(sizeof(Block) == 128 && sizeof(QRow) == 32 && sizeof(c4_sample_rec) == 64, "layout");
+
+enum : uint32_t { kIdle = 0, kActive = 1 };
+enum : int { CTR_SIMS = 0, CTR_S, CTR_K, CTR_E, CTR_MOVES, CTR_DONE, CTR_SKIPPED, CTR_SAMPLES, CTR_N };
+
+struct Globals {             // one small device struct of cross-wave words
+  unsigned long long queue_head;   // next game ordinal to start
+  unsigned long long games_done;
+  uint32_t error;            // first error status
+  uint32_t error_slot;
+};
+
+struct Params {
+  Slot* slots;
+  Block* blocks;
+  QRow* qrows;
+  unsigned long long* wave_ctr;  // [n_waves][CTR_N]
+  Globals* glob;
+  const c4_game_metadata* reqs;
+  const uint64_t* start_mask;    // may be null
+  const uint64_t* start_value;
+  c4_sample_rec* samples;        // [n_games][43]
+  uint32_t* sample_counts;       // [n_games]
+  void* planes;
+  const float* logprobs;
+  const float* q;
+  unsigned long long n_games;
+  uint32_t n_slots;
+  uint32_t blocks_per_slot;
+  uint32_t n_iter;
+  float c_exploration;
+  float c_ply_penalty;
+  uint32_t flags;
+};
+
+// ------------------------------------------------------------------------------------------
+// 8-lane group helpers
+// ------------------------------------------------------------------------------------------
+C4_DEV uint32_t shfl_u32(uint32_t v, int src_lane) { return (uint32_t)__shfl((int)v, src_lane, 64); }
+C4_DEV float shfl_f32(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+C4_DEV void raise_error(const Params& p, Slot* st, uint32_t g, uint32_t code) {
+  st->status = code;
+  if (atomicCAS(&p.glob->error, 0u, code) == 0u) p.glob->error_slot = g;
+}
+
+template <typename PlaneT>
+C4_DEV void store_plane(void* base, size_t idx, uint32_t bit);
+template <>
+C4_DEV void store_plane<float>(void* base, size_t idx, uint32_t bit) {
+  ((float*)base)[idx] = bit ? 1.0f : 0.0f;
+}
+template <>
+C4_DEV void store_plane<uint16_t>(void* base, size_t idx, uint32_t bit) {
+  ((uint16_t*)base)[idx] = bit ? (uint16_t)0x3F80 : (uint16_t)0;  // bf16 1.0 / 0.0
+}
+
+// Put game `ordinal` on a slot: MctsGame::new_from_pos (mcts.rs:48-56).  Called by all 8 lanes.
+C4_DEV void reset_slot(const Params& p, Slot* st, Block* blocks, QRow* qrows, uint32_t sub, unsigned long long ordinal) {
+  const uint64_t m = p.start_mask ? p.start_mask[ordinal] : 0ull;
+  const uint64_t v = p.start_value ? p.start_value[ordinal] : 0ull;
+  // block 0 holds only the root's own entry (prior 1.0, mcts.rs:49) in column 0
+  Entry e;
+  e.n = 0; e.q_pen = 0.0f; e.prior = (sub == 0) ? 1.0f : 0.0f; e.child = 0;
+  blocks[0].e[sub] = e;
+  qrows[0].q_nopen[sub] = 0.0f;
+  if (sub == 0) {
+    st->root_mask = m; st->root_value = v;
+    st->leaf_mask = m; st->leaf_value = v;
+    st->game_id = p.reqs[ordinal].game_id;
+    st->ordinal = (uint32_t)ordinal;
+    st->status = kActive;
+    st->root_ref = 0; st->root_block = 0; st->root_n = 0;
+    st->depth = 0; st->n_blocks = 1; st->n_moves = 0;
+    st->path[0] = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: start -- the state after self_play.rs:55-58 (every slot holds a fresh game whose leaf is
+// its start position) with the first leaves written to the evaluator's input tensor.
+// ------------------------------------------------------------------------------------------
+template <typename PlaneT>
+__global__ __launch_bounds__(64) void c4_start_kernel(Params p) {
+  const uint32_t sub = threadIdx.x & 7;
+  const uint32_t g = blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
+  if (g >= p.n_slots) return;
+  Slot* st = p.slots + g;
+  Block* blocks = p.blocks + (size_t)g * p.blocks_per_slot;
+  QRow* qrows = p.qrows + (size_t)g * p.blocks_per_slot;
+  uint64_t m = 0, v = 0;
+  if (g < p.n_games) {
+    reset_slot(p, st, blocks, qrows, sub, g);
+    m = p.start_mask ? p.start_mask[g] : 0ull;
+    v = p.start_value ? p.start_value[g] : 0ull;
+  } else if (sub == 0) {
+    st->status = kIdle;
+    st->ordinal = 0xFFFFFFFFu;
+  }
+  for (uint32_t e = sub; e < C4_PLANES_LEN; e += 8) store_plane<PlaneT>(p.planes, (size_t)g * C4_PLANES_LEN + e, c4::plane_bit(m, v, e));
+}
+
+// ------------------------------------------------------------------------------------------
+// K2-K5 fused: one MCTS simulation for every resident game.
+//   expand (mcts.rs:114-132, softmax mcts.rs:416-434)  ->  backup (mcts.rs:137-155)
+//   -> gate / move / finish / refill (self_play.rs:283-308, mcts.rs:187-222, 271-313)
+//   -> select (mcts.rs:160-183)  ->  encode the new leaf (c4r.rs:378-392)
+// ------------------------------------------------------------------------------------------
+template <typename PlaneT>
+__global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t sub = lane & 7;
+  const int gbase = (int)(lane & ~7u);
+  const uint32_t g = blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
+
+  unsigned long long c_sims = 0, c_S = 0, c_K = 0, c_E = 0, c_moves = 0, c_done = 0, c_skipped = 0, c_samples = 0;
+
+  Slot* st = p.slots + (g < p.n_slots ? g : 0);
+  bool active = (g < p.n_slots) && (st->status == kActive);
+
+  if (active) {
+    Block* blocks = p.blocks + (size_t)g * p.blocks_per_slot;
+    QRow* qrows = p.qrows + (size_t)g * p.blocks_per_slot;
+
+    uint64_t leaf_mask = st->leaf_mask, leaf_value = st->leaf_value;
+    uint64_t rmask = st->root_mask, rvalue = st->root_value;
+    uint32_t depth = st->depth;
+    uint32_t n_blocks = st->n_blocks;
+    uint32_t root_ref = st->root_ref;
+    uint32_t root_block = st->root_block;
+    uint32_t n_moves = st->n_moves;
+    const uint32_t leaf_ref = st->path[depth];
+    uint32_t err = 0;
+
+    // ---------------- on_received_policy: terminal value or expansion -------------------
+    float v_pen, v_nopen;
+    const uint32_t term = c4::terminal_state(leaf_mask, leaf_value);
+    if (term) {
+      c4::terminal_value(term, leaf_mask, p.c_ply_penalty, v_pen, v_nopen);  // NN output ignored (mcts.rs:92-98)
+    } else {
+      const uint32_t legal = c4::legal_mask(leaf_mask);
+      const bool is_legal = sub < 7 && ((legal >> sub) & 1u);
+      float logit = __uint_as_float(0xff800000u);                             // mask_policy, c4r.rs:272-286
+      if (is_legal) logit = p.logprobs[(size_t)g * 7 + sub];
+      float mx = logit;                                                       // f32::max fold (NaN-ignoring)
+      mx = c4::rust_max(mx, shfl_f32(mx, (int)(lane ^ 1)));
+      mx = c4::rust_max(mx, shfl_f32(mx, (int)(lane ^ 2)));
+      mx = c4::rust_max(mx, shfl_f32(mx, (int)(lane ^ 4)));
+      if (__builtin_isinf(mx)) err = C4_ERR_DEGENERATE_POLICY;                // mcts.rs:421-425
+      const float ex = c4::c4_expf(logit - mx);
+      float sum = 0.0f;                                                       // left-to-right, mcts.rs:432
+      for (int i = 0; i < 7; i++) sum = sum + shfl_f32(ex, gbase + i);
+      const float prior = ex / sum;
+      const uint32_t nb = n_blocks;
+      if (nb >= p.blocks_per_slot) err = err ? err : C4_ERR_ARENA_OVERFLOW;
+      if (!err) {
+        Entry e;                                                              // Node::new, mcts.rs:345-355
+        e.n = (sub == 7) ? legal : 0u;
+        e.q_pen = 0.0f;
+        e.prior = (sub == 7) ? 0.0f : prior;
+        e.child = 0;
+        blocks[nb].e[sub] = e;
+        qrows[nb].q_nopen[sub] = 0.0f;
+        if (sub == 0) blocks[leaf_ref >> 3].e[leaf_ref & 7].child = nb;       // leaf.children = Some(..)
+        if (depth == 0) root_block = nb;
+        n_blocks = nb + 1;
+        c_E = 1;
+      }
+      v_pen = p.q[(size_t)g * 2 + 0];
+      v_nopen = p.q[(size_t)g * 2 + 1];
+    }
+
+    if (err) {
+      if (sub == 0) raise_error(p, st, g, err);
+    } else {
+      // ---------------- backpropagate_value: leaf -> root along the recorded path ----------
+      uint32_t root_n = 0;
+      for (uint32_t d = sub; d <= depth; d += 8) {
+        const uint32_t ref = st->path[d];
+        Entry* e = &blocks[ref >> 3].e[ref & 7];
+        float* qn = &qrows[ref >> 3].q_nopen[ref & 7];
+        const bool odd = ((depth - d) & 1u) != 0;                             // value negated per step up
+        const uint32_t n1 = e->n + 1;
+        const float q1 = e->q_pen + (odd ? -v_pen : v_pen);
+        const float q2 = *qn + (odd ? -v_nopen : v_nopen);
+        e->n = n1;
+        e->q_pen = q1;
+        *qn = q2;
+        if (d == 0) root_n = n1;
+      }
+      root_n = shfl_u32(root_n, gbase);
+      c_sims = 1;
+      c_K = depth + 1;
+      // stores above are read back below through other lanes of this wave
+      __threadfence_block();
+
+      // ---------------- gate: self_play.rs:283-308 ------------------------------------------
+      bool finished = false;
+      if (root_n >= p.n_iter && !(p.flags & C4_FLAG_NO_MOVES)) {
+        const size_t rec0 = (size_t)st->ordinal * C4_MAX_SAMPLES_PER_GAME;
+        uint32_t rterm = c4::terminal_state(rmask, rvalue);  // non-zero only for a terminal START position
+        uint32_t retained = p.n_iter;
+        if (!rterm) {
+          // root_policy (mcts.rs:396-412): child visit counts / their sum
+          const Entry re = blocks[root_block].e[sub];
+          const float cnt = (sub < 7) ? (float)re.n : 0.0f;
+          float w[7];
+          float csum = 0.0f;
+          for (int i = 0; i < 7; i++) { w[i] = shfl_f32(cnt, gbase + i); csum = csum + w[i]; }
+          float pol[7];
+          for (int i = 0; i < 7; i++) pol[i] = (csum == 0.0f) ? (1.0f / 7.0f) : (w[i] / csum);
+          // make_random_move (mcts.rs:214-222)
+          const float temperature = c4::temperature_for_ply((uint32_t)__popcll(rmask));
+          float tp[7];
+          c4::apply_temperature(pol, temperature, tp);
+          const uint64_t seed = st->game_id * (uint64_t)(42 + n_moves);
+          const int col = c4::weighted_index(tp, c4::rng_first_u32(seed));
+          if (col < 0) {
+            err = C4_ERR_DEGENERATE_POLICY;
+          } else if (!((c4::legal_mask(rmask) >> col) & 1u)) {
+            err = C4_ERR_ILLEGAL_MOVE;                                        // mcts.rs:196-200 expect()
+          } else {
+            // make_move (mcts.rs:187-206): record (root position, untempered policy), re-root
+            c4_sample_rec* rec = p.samples + rec0 + n_moves;
+            if (sub < 7) rec->policy[sub] = pol[sub];
+            if (sub == 7) {
+              rec->game_id = st->game_id; rec->mask = rmask; rec->value = rvalue; rec->meta = n_moves;
+            }
+            retained = shfl_u32(re.n, gbase + col);
+            const uint32_t child_blk = shfl_u32(re.child, gbase + col);
+            root_ref = (root_block << 3) | (uint32_t)col;
+            root_block = child_blk;
+            root_n = retained;
+            c4::make_move(rmask, rvalue, (uint32_t)col);
+            n_moves += 1;
+            c_moves = 1;
+            rterm = c4::terminal_state(rmask, rvalue);
+          }
+        }
+        if (!err && rterm) {
+          // Game over (self_play.rs:302-308).  After a move INTO a terminal position the
+          // reference keeps evaluating that root until it has n visits (self_play.rs:283-301);
+          // those sims cannot change the samples (mcts.rs:271-313), so the game is closed now
+          // and the skipped sims are counted.
+          c_skipped = (p.n_iter > retained) ? (p.n_iter - retained) : 0;
+          float tq_pen, tq_nopen;
+          c4::terminal_value(rterm, rmask, p.c_ply_penalty, tq_pen, tq_nopen);
+          // to_result (mcts.rs:271-313): sample i gets +q iff (M - i) is even
+          for (uint32_t i = sub; i < n_moves; i += 8) {
+            const bool neg = ((n_moves - i) & 1u) != 0;
+            p.samples[rec0 + i].q_penalty = neg ? -tq_pen : tq_pen;
+            p.samples[rec0 + i].q_no_penalty = neg ? -tq_nopen : tq_nopen;
+          }
+          c4_sample_rec* tr = p.samples + rec0 + n_moves;
+          if (sub < 7) tr->policy[sub] = 1.0f / 7.0f;                         // UNIFORM_POLICY, mcts.rs:45
+          if (sub == 7) {
+            tr->game_id = st->game_id; tr->mask = rmask; tr->value = rvalue;
+            tr->q_penalty = tq_pen; tr->q_no_penalty = tq_nopen; tr->meta = n_moves | (1u << 16);
+            p.sample_counts[st->ordinal] = n_moves + 1;
+          }
+          c_done = 1;
+          c_samples = n_moves + 1;
+          finished = true;
+        }
+      }
+
+      if (err) {
+        if (sub == 0) raise_error(p, st, g, err);
+      } else {
+        if (finished) {
+          // replace the finished game by the next one of the request list (keeps the batch full)
+          unsigned long long next = 0;
+          if (sub == 0) {
+            atomicAdd(&p.glob->games_done, 1ull);
+            next = atomicAdd(&p.glob->queue_head, 1ull);
+          }
+          next = ((unsigned long long)shfl_u32((uint32_t)(next >> 32), gbase) << 32) | shfl_u32((uint32_t)next, gbase);
+          if (next < p.n_games) {
+            reset_slot(p, st, blocks, qrows, sub, next);
+            __threadfence_block();
+            rmask = p.start_mask ? p.start_mask[next] : 0ull;
+            rvalue = p.start_value ? p.start_value[next] : 0ull;
+            root_ref = 0; root_block = 0; root_n = 0; n_blocks = 1; n_moves = 0;
+          } else {
+            active = false;
+            if (sub == 0) { st->status = kIdle; st->ordinal = 0xFFFFFFFFu; }
+          }
+        }
+        if (active) {
+          // ---------------- select_new_leaf (mcts.rs:160-183) -------------------------------
+          uint64_t m = rmask, v = rvalue;
+          uint32_t blk = root_block, np = root_n, d = 0;
+          while (blk != 0 && d + 1 < kMaxPath) {
+            const Entry ce = blocks[blk].e[sub];
+            const uint32_t legal = c4::legal_mask(m);
+            const bool ok = sub < 7 && ((legal >> sub) & 1u);
+            float score = 0.0f;
+            if (ok) {
+              // uct_value (mcts.rs:359-388); c4_logf(1) == 0 makes every first-level score -0+0
+              const float nf = (float)ce.n + 1.0f;
+              const float qv = ce.q_pen / nf;
+              float ex = c4::c4_logf((float)np) / nf;
+              ex = __builtin_sqrtf(ex);
+              ex = ex * (ce.prior + 1e-8f);
+              const float cx = p.c_exploration * ex;
+              score = -qv + cx;
+            }
+            // max_by_key keeps the LAST maximum (mcts.rs:165-173); NaN panics (utils.rs:12)
+            const bool isn = ok && (score != score);
+            const unsigned long long nan_ballot = __ballot(isn) >> gbase & 0xFFull;
+            if (nan_ballot && __popc(legal) >= 2) { err = C4_ERR_NAN_IN_TREE; break; }
+            float bs = score; int bi = ok ? (int)sub : -1;
+            for (int off = 1; off < 8; off <<= 1) {
+              const float os = shfl_f32(bs, (int)(lane ^ off));
+              const int oi = (int)shfl_u32((uint32_t)bi, (int)(lane ^ off));
+              const bool take = (oi >= 0) && (bi < 0 || os > bs || (os == bs && oi > bi));
+              if (take) { bs = os; bi = oi; }
+            }
+            const uint32_t best = (uint32_t)bi;
+            np = shfl_u32(ce.n, gbase + (int)best);
+            const uint32_t next_blk = shfl_u32(ce.child, gbase + (int)best);
+            c4::make_move(m, v, best);
+            d += 1;
+            if (sub == 0) st->path[d] = (blk << 3) | best;
+            blk = next_blk;
+            c_S += 1;
+          }
+          if (err) {
+            if (sub == 0) raise_error(p, st, g, err);
+          } else {
+            if (sub == 0) {
+              st->root_mask = rmask; st->root_value = rvalue;
+              st->leaf_mask = m; st->leaf_value = v;
+              st->root_ref = root_ref; st->root_block = root_block; st->root_n = root_n;
+              st->depth = d; st->n_blocks = n_blocks; st->n_moves = n_moves;
+              st->path[0] = root_ref;
+            }
+            // ---------------- leaf -> evaluator input (c4r.rs:378-392) ----------------------
+            for (uint32_t e = sub; e < C4_PLANES_LEN; e += 8)
+              store_plane<PlaneT>(p.planes, (size_t)g * C4_PLANES_LEN + e, c4::plane_bit(m, v, e));
+          }
+        }
+      }
+    }
+  }
+
+  // ---------------- per-wavefront counters (one writer per row: no atomics) -----------------
+  unsigned long long vals[CTR_N] = {c_sims, c_S, c_K, c_E, c_moves, c_done, c_skipped, c_samples};
+  for (int k = 0; k < CTR_N; k++) {
+    unsigned long long x = vals[k];  // uniform within a game's 8 lanes: summing lanes l, l^8, l^16, l^32 adds the 8 games
+    for (int off = 8; off < 64; off <<= 1) {
+      const uint32_t lo = shfl_u32((uint32_t)x, (int)(lane ^ off));
+      const uint32_t hi = shfl_u32((uint32_t)(x >> 32), (int)(lane ^ off));
+      x += ((unsigned long long)hi << 32) | lo;
+    }
+    vals[k] = x;
+  }
+  if (lane < CTR_N) {
+    unsigned long long add = 0;
+    for (int k = 0; k < CTR_N; k++) add = (lane == (uint32_t)k) ? vals[k] : add;
+    if (add) p.wave_ctr[(size_t)blockIdx.x * CTR_N + lane] += add;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Element-wise kernels (SURVEY 8a K1 and the arithmetic pieces) for the parity tests
+// ------------------------------------------------------------------------------------------
+__global__ void k_pos_ops(const uint64_t* mask, const uint64_t* value, const int32_t* col, uint64_t n, float c_ply,
+                          uint64_t* om, uint64_t* ov, uint32_t* olegal, uint32_t* oterm, float* oq) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t m = mask[i], v = value[i];
+  const uint32_t legal = c4::legal_mask(m);
+  const uint32_t t = c4::terminal_state(m, v);
+  float a = 0.0f, b = 0.0f;
+  if (t) c4::terminal_value(t, m, c_ply, a, b);
+  olegal[i] = legal;
+  oterm[i] = t;
+  oq[2 * i] = a;
+  oq[2 * i + 1] = b;
+  const int32_t c = col[i];
+  if (c >= 0 && c < 7 && ((legal >> c) & 1u)) {
+    c4::make_move(m, v, (uint32_t)c);
+    om[i] = m; ov[i] = v;
+  } else {
+    om[i] = 0; ov[i] = 0;  // make_move returns None (c4r.rs:71)
+  }
+}
+
+template <typename PlaneT>
+__global__ void k_encode(const uint64_t* mask, const uint64_t* value, uint64_t n, void* planes) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * C4_PLANES_LEN) return;
+  const uint64_t g = i / C4_PLANES_LEN;
+  const uint32_t e = (uint32_t)(i % C4_PLANES_LEN);
+  store_plane<PlaneT>(planes, i, c4::plane_bit(mask[g], value[g], e));
+}
+
+__global__ void k_expf_logf(const float* x, uint64_t n, int which, float* y) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  y[i] = which ? c4::c4_logf(x[i]) : c4::c4_expf(x[i]);
+}
+
+__global__ void k_softmax7(const float* logits, const uint32_t* legal, uint64_t n, float* out, uint32_t* err) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float l[7], o[7];
+  for (int c = 0; c < 7; c++) {
+    l[c] = logits[7 * i + c];
+    if (legal && !((legal[i] >> c) & 1u)) l[c] = __uint_as_float(0xff800000u);
+  }
+  const bool ok = c4::softmax7(l, o);
+  err[i] = ok ? 0u : (uint32_t)C4_ERR_DEGENERATE_POLICY;
+  for (int c = 0; c < 7; c++) out[7 * i + c] = ok ? o[c] : 0.0f;
+}
+
+__global__ void k_temperature(const float* policy, const float* t, uint64_t n, float* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p[7], o[7];
+  for (int c = 0; c < 7; c++) p[c] = policy[7 * i + c];
+  c4::apply_temperature(p, t[i], o);
+  for (int c = 0; c < 7; c++) out[7 * i + c] = o[c];
+}
+
+__global__ void k_sample_move(const uint64_t* game_id, const uint32_t* n_moves, const float* policy, const float* t,
+                              uint64_t n, int32_t* out_col, uint32_t* out_u32) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p[7], o[7];
+  for (int c = 0; c < 7; c++) p[c] = policy[7 * i + c];
+  c4::apply_temperature(p, t[i], o);
+  const uint32_t u = c4::rng_first_u32(game_id[i] * (uint64_t)(42 + n_moves[i]));
+  out_col[i] = c4::weighted_index(o, u);
+  if (out_u32) out_u32[i] = u;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(C4_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+  } while (0)
+
+}  // namespace
+
+struct c4_session {
+  c4_config cfg{};
+  Params p{};
+  hipStream_t stream = nullptr;
+  uint32_t n_waves = 0;
+  bool bound = false, have_games = false;
+  uint64_t n_games = 0;
+  c4_game_metadata* reqs_dev = nullptr;
+  uint64_t* start_mask_dev = nullptr;
+  uint64_t* start_value_dev = nullptr;
+  // pinned probe buffer for c4_session_poll
+  Globals* probe_host = nullptr;
+  hipEvent_t probe_event = nullptr;
+  bool probe_pending = false;
+  uint64_t probe_done = 0;
+  uint32_t probe_error = 0;
+};
+
+extern "C" {
+
+const char* c4_last_error_string(void) { return g_last_error.c_str(); }
+
+int c4_device_count(int* out) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) n = 0;
+  if (out) *out = n;
+  return C4_OK;
+}
+
+int c4_session_create(const c4_config* cfg, c4_session** out) {
+  if (!cfg || !out) return fail(C4_ERR_BAD_ARG, "null argument");
+  if (cfg->n_slots == 0) return fail(C4_ERR_BAD_ARG, "n_slots must be > 0");
+  if (cfg->planes_dtype > 1) return fail(C4_ERR_BAD_ARG, "planes_dtype must be 0 (f32) or 1 (bf16)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(C4_ERR_NO_DEVICE, "no HIP device visible");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(C4_ERR_BAD_ARG, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(cfg->device));
+  c4_session* s = new c4_session();
+  s->cfg = *cfg;
+  uint64_t bps = cfg->blocks_per_slot;
+  if (bps == 0) bps = 43ull * (cfg->n_mcts_iterations ? cfg->n_mcts_iterations : 1) + 8;
+  if (bps < 2) bps = 2;
+  if (bps >= (1ull << 29)) { delete s; return fail(C4_ERR_BAD_ARG, "blocks_per_slot too large"); }
+  s->cfg.blocks_per_slot = (uint32_t)bps;
+  const size_t n = cfg->n_slots;
+  s->n_waves = (uint32_t)((n + 7) / 8);
+  Params& p = s->p;
+  p.n_slots = cfg->n_slots;
+  p.blocks_per_slot = (uint32_t)bps;
+  p.n_iter = cfg->n_mcts_iterations;
+  p.c_exploration = cfg->c_exploration;
+  p.c_ply_penalty = cfg->c_ply_penalty;
+  p.flags = cfg->flags;
+  hipError_t e;
+  if ((e = hipMalloc(&p.slots, n * sizeof(Slot))) != hipSuccess ||
+      (e = hipMalloc(&p.blocks, n * bps * sizeof(Block))) != hipSuccess ||
+      (e = hipMalloc(&p.qrows, n * bps * sizeof(QRow))) != hipSuccess ||
+      (e = hipMalloc(&p.wave_ctr, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMalloc(&p.glob, sizeof(Globals))) != hipSuccess ||
+      (e = hipHostMalloc(&s->probe_host, sizeof(Globals))) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&s->probe_event, hipEventDisableTiming)) != hipSuccess) {
+    std::string msg = std::string("allocating session (") + std::to_string((n * bps * (sizeof(Block) + sizeof(QRow))) >> 20) +
+                      " MiB of tree arena): " + hipGetErrorString(e);
+    c4_session_destroy(s);
+    return fail(C4_ERR_HIP, msg);
+  }
+  HIP_TRY(hipMemset(p.slots, 0, n * sizeof(Slot)));
+  HIP_TRY(hipMemset(p.glob, 0, sizeof(Globals)));
+  HIP_TRY(hipMemset(p.wave_ctr, 0, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long)));
+  memset(s->probe_host, 0, sizeof(Globals));
+  *out = s;
+  return C4_OK;
+}
+
+int c4_session_destroy(c4_session* s) {
+  if (!s) return C4_OK;
+  (void)hipSetDevice(s->cfg.device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream); else (void)hipDeviceSynchronize();
+  (void)hipFree(s->p.slots); (void)hipFree(s->p.blocks); (void)hipFree(s->p.qrows); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob);
+  (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts);
+  (void)hipFree(s->reqs_dev); (void)hipFree(s->start_mask_dev); (void)hipFree(s->start_value_dev);
+  if (s->probe_host) (void)hipHostFree(s->probe_host);
+  if (s->probe_event) (void)hipEventDestroy(s->probe_event);
+  delete s;
+  return C4_OK;
+}
+
+int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n_games,
+                         const uint64_t* start_masks, const uint64_t* start_values) {
+  if (!s || (!reqs && n_games)) return fail(C4_ERR_BAD_ARG, "null argument");
+  if ((start_masks == nullptr) != (start_values == nullptr)) return fail(C4_ERR_BAD_ARG, "start_masks and start_values go together");
+  if (n_games >= (1ull << 32) - 1) return fail(C4_ERR_BAD_ARG, "too many games for one session");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  (void)hipFree(s->reqs_dev); (void)hipFree(s->start_mask_dev); (void)hipFree(s->start_value_dev);
+  (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts);
+  s->reqs_dev = nullptr; s->start_mask_dev = s->start_value_dev = nullptr;
+  s->p.samples = nullptr; s->p.sample_counts = nullptr;
+  const size_t ng = n_games ? n_games : 1;
+  HIP_TRY(hipMalloc(&s->reqs_dev, ng * sizeof(c4_game_metadata)));
+  HIP_TRY(hipMalloc(&s->p.samples, ng * C4_MAX_SAMPLES_PER_GAME * sizeof(c4_sample_rec)));
+  HIP_TRY(hipMalloc(&s->p.sample_counts, ng * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(s->p.sample_counts, 0, ng * sizeof(uint32_t)));
+  if (n_games) HIP_TRY(hipMemcpy(s->reqs_dev, reqs, n_games * sizeof(c4_game_metadata), hipMemcpyHostToDevice));
+  if (start_masks && n_games) {
+    HIP_TRY(hipMalloc(&s->start_mask_dev, n_games * 8));
+    HIP_TRY(hipMalloc(&s->start_value_dev, n_games * 8));
+    HIP_TRY(hipMemcpy(s->start_mask_dev, start_masks, n_games * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->start_value_dev, start_values, n_games * 8, hipMemcpyHostToDevice));
+  }
+  Globals g0{};
+  g0.queue_head = n_games < s->cfg.n_slots ? n_games : s->cfg.n_slots;
+  HIP_TRY(hipMemcpy(s->p.glob, &g0, sizeof g0, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(s->p.wave_ctr, 0, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long)));
+  s->p.reqs = s->reqs_dev;
+  s->p.start_mask = s->start_mask_dev;
+  s->p.start_value = s->start_value_dev;
+  s->p.n_games = n_games;
+  s->n_games = n_games;
+  s->have_games = true;
+  s->probe_pending = false; s->probe_done = 0; s->probe_error = 0;
+  return C4_OK;
+}
+
+int c4_session_bind_io(c4_session* s, void* planes_dev, const float* logprobs_dev, const float* q_dev, void* stream) {
+  if (!s || !planes_dev || !logprobs_dev || !q_dev) return fail(C4_ERR_BAD_ARG, "null argument");
+  s->p.planes = planes_dev;
+  s->p.logprobs = logprobs_dev;
+  s->p.q = q_dev;
+  s->stream = (hipStream_t)stream;
+  s->bound = true;
+  return C4_OK;
+}
+
+int c4_session_start(c4_session* s) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  if (!s->bound || !s->have_games) return fail(C4_ERR_NOT_BOUND, "bind_io and set_games must precede start");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  if (s->cfg.planes_dtype == 0)
+    hipLaunchKernelGGL(c4_start_kernel<float>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+  else
+    hipLaunchKernelGGL(c4_start_kernel<uint16_t>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+int c4_session_step(c4_session* s) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  if (!s->bound || !s->have_games) return fail(C4_ERR_NOT_BOUND, "bind_io and set_games must precede step");
+  if (s->cfg.planes_dtype == 0)
+    hipLaunchKernelGGL(c4_step_kernel<float>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+  else
+    hipLaunchKernelGGL(c4_step_kernel<uint16_t>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+int c4_session_counters(c4_session* s, c4_counters* out) {
+  if (!s || !out) return fail(C4_ERR_BAD_ARG, "null argument");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  std::vector<unsigned long long> h((size_t)s->n_waves * CTR_N);
+  HIP_TRY(hipMemcpy(h.data(), s->p.wave_ctr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  Globals g{};
+  HIP_TRY(hipMemcpy(&g, s->p.glob, sizeof g, hipMemcpyDeviceToHost));
+  unsigned long long sum[CTR_N] = {0};
+  for (size_t w = 0; w < s->n_waves; w++)
+    for (int k = 0; k < CTR_N; k++) sum[k] += h[w * CTR_N + k];
+  memset(out, 0, sizeof *out);
+  out->sims = sum[CTR_SIMS]; out->select_levels = sum[CTR_S]; out->backup_nodes = sum[CTR_K];
+  out->expansions = sum[CTR_E]; out->moves = sum[CTR_MOVES]; out->games_done = sum[CTR_DONE];
+  out->ref_skipped_sims = sum[CTR_SKIPPED]; out->samples = sum[CTR_SAMPLES];
+  out->games_started = g.queue_head < s->n_games ? g.queue_head : s->n_games;
+  out->error = g.error; out->error_slot = g.error_slot;
+  return C4_OK;
+}
+
+int c4_session_poll(c4_session* s, uint64_t* games_done, uint32_t* error) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  if (s->probe_pending && hipEventQuery(s->probe_event) == hipSuccess) {
+    s->probe_done = s->probe_host->games_done;
+    s->probe_error = s->probe_host->error;
+    s->probe_pending = false;
+  }
+  if (!s->probe_pending) {
+    HIP_TRY(hipMemcpyAsync(s->probe_host, s->p.glob, sizeof(Globals), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipEventRecord(s->probe_event, s->stream));
+    s->probe_pending = true;
+  }
+  if (games_done) *games_done = s->probe_done;
+  if (error) *error = s->probe_error;
+  return C4_OK;
+}
+
+int c4_session_sample_counts(c4_session* s, uint32_t* counts_host, uint64_t n_games) {
+  if (!s || !counts_host) return fail(C4_ERR_BAD_ARG, "null argument");
+  if (n_games != s->n_games) return fail(C4_ERR_BAD_ARG, "n_games does not match set_games");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (n_games) HIP_TRY(hipMemcpy(counts_host, s->p.sample_counts, n_games * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return C4_OK;
+}
+
+int c4_session_drain_samples(c4_session* s, c4_sample_rec* dst_host, uint64_t cap, uint64_t* n_written) {
+  if (!s || !n_written) return fail(C4_ERR_BAD_ARG, "null argument");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  std::vector<uint32_t> counts(s->n_games ? s->n_games : 1);
+  if (s->n_games) HIP_TRY(hipMemcpy(counts.data(), s->p.sample_counts, s->n_games * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < s->n_games; i++) total += counts[i];
+  *n_written = total;
+  if (!dst_host) return C4_OK;  // size query
+  if (cap < total) return fail(C4_ERR_BAD_ARG, "destination too small");
+  // copy runs of consecutive finished games with one transfer each
+  uint64_t off = 0, i = 0;
+  std::vector<c4_sample_rec> tmp;
+  const uint64_t chunk_games = 4096;
+  while (i < s->n_games) {
+    const uint64_t j = (i + chunk_games < s->n_games) ? i + chunk_games : s->n_games;
+    tmp.resize((j - i) * C4_MAX_SAMPLES_PER_GAME);
+    HIP_TRY(hipMemcpy(tmp.data(), s->p.samples + i * C4_MAX_SAMPLES_PER_GAME, tmp.size() * sizeof(c4_sample_rec), hipMemcpyDeviceToHost));
+    for (uint64_t k = i; k < j; k++) {
+      memcpy(dst_host + off, tmp.data() + (k - i) * C4_MAX_SAMPLES_PER_GAME, (size_t)counts[k] * sizeof(c4_sample_rec));
+      off += counts[k];
+    }
+    i = j;
+  }
+  return C4_OK;
+}
+
+int c4_session_sample_store(c4_session* s, const c4_sample_rec** recs_dev, const uint32_t** counts_dev, uint64_t* n_games) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  if (recs_dev) *recs_dev = s->p.samples;
+  if (counts_dev) *counts_dev = s->p.sample_counts;
+  if (n_games) *n_games = s->n_games;
+  return C4_OK;
+}
+
+int c4_session_root_stats(c4_session* s, uint32_t slot, float policy[7], float* q_penalty, float* q_no_penalty,
+                          uint64_t* visit_count, uint64_t* root_mask, uint64_t* root_value) {
+  if (!s || slot >= s->cfg.n_slots) return fail(C4_ERR_BAD_ARG, "bad slot");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  Slot st;
+  HIP_TRY(hipMemcpy(&st, s->p.slots + slot, sizeof st, hipMemcpyDeviceToHost));
+  const size_t base = (size_t)slot * s->cfg.blocks_per_slot;
+  Block rb;
+  QRow rq;
+  HIP_TRY(hipMemcpy(&rb, s->p.blocks + base + (st.root_ref >> 3), sizeof rb, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&rq, s->p.qrows + base + (st.root_ref >> 3), sizeof rq, hipMemcpyDeviceToHost));
+  const Entry& re = rb.e[st.root_ref & 7];
+  // mcts.rs:359-367: q_sum / (visit_count as f32 + 1.0)
+  const float nf = (float)re.n + 1.0f;
+  if (q_penalty) *q_penalty = re.q_pen / nf;
+  if (q_no_penalty) *q_no_penalty = rq.q_nopen[st.root_ref & 7] / nf;
+  if (visit_count) *visit_count = re.n;
+  if (root_mask) *root_mask = st.root_mask;
+  if (root_value) *root_value = st.root_value;
+  if (policy) {
+    // mcts.rs:396-412
+    float cnt[7] = {0, 0, 0, 0, 0, 0, 0}, sum = 0.0f;
+    if (re.child) {
+      Block cb;
+      HIP_TRY(hipMemcpy(&cb, s->p.blocks + base + re.child, sizeof cb, hipMemcpyDeviceToHost));
+      for (int c = 0; c < 7; c++) cnt[c] = (float)cb.e[c].n;
+    }
+    for (int c = 0; c < 7; c++) sum = sum + cnt[c];
+    for (int c = 0; c < 7; c++) policy[c] = (sum == 0.0f) ? (1.0f / 7.0f) : cnt[c] / sum;
+  }
+  return C4_OK;
+}
+
+int c4_session_leaves(c4_session* s, uint64_t* masks_host, uint64_t* values_host, uint32_t* status_host,
+                      uint32_t* ordinals_host) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  std::vector<Slot> h(s->cfg.n_slots);
+  HIP_TRY(hipMemcpy(h.data(), s->p.slots, h.size() * sizeof(Slot), hipMemcpyDeviceToHost));
+  for (uint32_t g = 0; g < s->cfg.n_slots; g++) {
+    if (masks_host) masks_host[g] = h[g].leaf_mask;
+    if (values_host) values_host[g] = h[g].leaf_value;
+    if (status_host) status_host[g] = h[g].status;
+    if (ordinals_host) ordinals_host[g] = h[g].ordinal;
+  }
+  return C4_OK;
+}
+
+// ---- element-wise entry points ----
+static inline dim3 grid_for(uint64_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+int c4_pos_ops(const uint64_t* mask_dev, const uint64_t* value_dev, const int32_t* col_dev, uint64_t n, float c_ply_penalty,
+               uint64_t* out_mask_dev, uint64_t* out_value_dev, uint32_t* out_legal_dev, uint32_t* out_terminal_dev,
+               float* out_q_dev, void* stream) {
+  if (n == 0) return C4_OK;
+  hipLaunchKernelGGL(k_pos_ops, grid_for(n), dim3(256), 0, (hipStream_t)stream, mask_dev, value_dev, col_dev, n, c_ply_penalty,
+                     out_mask_dev, out_value_dev, out_legal_dev, out_terminal_dev, out_q_dev);
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+int c4_encode_planes(const uint64_t* mask_dev, const uint64_t* value_dev, uint64_t n, uint32_t planes_dtype, void* planes_dev, void* stream) {
+  if (n == 0) return C4_OK;
+  if (planes_dtype == 0)
+    hipLaunchKernelGGL(k_encode<float>, grid_for(n * C4_PLANES_LEN), dim3(256), 0, (hipStream_t)stream, mask_dev, value_dev, n, planes_dev);
+  else if (planes_dtype == 1)
+    hipLaunchKernelGGL(k_encode<uint16_t>, grid_for(n * C4_PLANES_LEN), dim3(256), 0, (hipStream_t)stream, mask_dev, value_dev, n, planes_dev);
+  else
+    return fail(C4_ERR_BAD_ARG, "planes_dtype must be 0 or 1");
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+int c4_expf_logf(const float* x_dev, uint64_t n, int which, float* y_dev, void* stream) {
+  if (n == 0) return C4_OK;
+  hipLaunchKernelGGL(k_expf_logf, grid_for(n), dim3(256), 0, (hipStream_t)stream, x_dev, n, which, y_dev);
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+int c4_softmax7(const float* logits_dev, const uint32_t* legal_dev, uint64_t n, float* out_dev, uint32_t* out_err_dev, void* stream) {
+  if (n == 0) return C4_OK;
+  hipLaunchKernelGGL(k_softmax7, grid_for(n), dim3(256), 0, (hipStream_t)stream, logits_dev, legal_dev, n, out_dev, out_err_dev);
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+int c4_apply_temperature(const float* policy_dev, const float* temperature_dev, uint64_t n, float* out_dev, void* stream) {
+  if (n == 0) return C4_OK;
+  hipLaunchKernelGGL(k_temperature, grid_for(n), dim3(256), 0, (hipStream_t)stream, policy_dev, temperature_dev, n, out_dev);
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+int c4_sample_move(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, const float* policy_dev, const float* temperature_dev,
+                   uint64_t n, int32_t* out_col_dev, uint32_t* out_u32_dev, void* stream) {
+  if (n == 0) return C4_OK;
+  hipLaunchKernelGGL(k_sample_move, grid_for(n), dim3(256), 0, (hipStream_t)stream, game_id_dev, n_moves_dev, policy_dev,
+                     temperature_dev, n, out_col_dev, out_u32_dev);
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+"""ConnectFourNet inference for the self-play evaluator (reference src/c4a0/nn.py).
+
+Only the forward pass is in scope: the reference evaluates leaves through
+`ConnectFourNet.forward_numpy` (nn.py:119-130), a host round trip per batch.  Here the same
+network runs as PyTorch-ROCm on the device that holds the trees, on the tensors the HIP step
+kernel reads and writes.
+
+* `ConnectFourNet` has the reference's module tree, so `state_dict()` keys are identical
+  (`conv.0.*`, `conv.{i}.block.{0,1,2}.*`, `fc_policy.*`, `fc_value.*`; nn.py:64-100,184-195)
+  and a reference checkpoint loads unchanged.
+* `InferenceNet` is the evaluator: BatchNorm folded into the preceding conv/linear (eval-mode
+  statistics), weights in bf16 (or f32), log-softmax/tanh in f32, outputs written into
+  caller-provided tensors; optionally captured in a HIP graph.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+N_COLS, N_ROWS = 7, 6
+
+
+@dataclass
+class ModelConfig:  # nn.py:16-38 (training-only fields omitted)
+    n_residual_blocks: int = 1
+    conv_filter_size: int = 32
+    n_policy_layers: int = 4
+    n_value_layers: int = 2
+
+
+class ResidualBlock(nn.Module):  # nn.py:184-195: x + ReLU(BN(Conv(Conv(x))))
+    def __init__(self, n_channels: int):
+        super().__init__()
+        self.block = nn.Sequential(
+            nn.Conv2d(n_channels, n_channels, kernel_size=3, padding=1),
+            nn.Conv2d(n_channels, n_channels, kernel_size=3, padding=1),
+            nn.BatchNorm2d(n_channels),
+            nn.ReLU(),
+        )
+
+    def forward(self, x):
+        return x + self.block(x)
+
+
+class ConnectFourNet(nn.Module):
+    def __init__(self, config: ModelConfig):
+        super().__init__()
+        self.config = config
+        c = config.conv_filter_size
+        self.conv = nn.Sequential(  # nn.py:64-70: first conv has no BN / ReLU
+            nn.Conv2d(2, c, kernel_size=3, padding=1),
+            *[ResidualBlock(c) for _ in range(config.n_residual_blocks)],
+        )
+        fc = c * N_ROWS * N_COLS  # nn.py:72,132-138
+        self.fc_policy = nn.Sequential(  # nn.py:75-86
+            *[nn.Sequential(nn.Linear(fc, fc), nn.BatchNorm1d(fc), nn.ReLU()) for _ in range(config.n_policy_layers - 1)],
+            nn.Linear(fc, N_COLS),
+            nn.LogSoftmax(dim=1),
+        )
+        self.fc_value = nn.Sequential(  # nn.py:89-100
+            *[nn.Sequential(nn.Linear(fc, fc), nn.BatchNorm1d(fc), nn.ReLU()) for _ in range(config.n_value_layers - 1)],
+            nn.Linear(fc, 2),
+            nn.Tanh(),
+        )
+
+    def forward(self, x) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:  # nn.py:109-117
+        x = self.conv(x)
+        x = x.reshape(x.shape[0], -1)  # "b c h w -> b (c h w)"
+        policy_logprobs = self.fc_policy(x)
+        q = self.fc_value(x)
+        return policy_logprobs, q[:, 0], q[:, 1]
+
+
+def _fold_bn(weight: torch.Tensor, bias: torch.Tensor, bn: nn.modules.batchnorm._BatchNorm):
+    """Eval-mode BN(y) = (y - mean) / sqrt(var + eps) * gamma + beta folded into y = W x + b."""
+    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    shape = [-1] + [1] * (weight.dim() - 1)
+    w = weight.detach().double() * scale.reshape(shape)
+    b = (bias.detach().double() - bn.running_mean.detach().double()) * scale + bn.bias.detach().double()
+    return w.float(), b.float()
+
+
+class InferenceNet:
+    """Device-resident evaluator: planes[G,2,6,7] -> (policy_logprobs[G,7] f32, q[G,2] f32)."""
+
+    def __init__(self, model: ConnectFourNet, device: torch.device, dtype: torch.dtype = torch.bfloat16):
+        self.device = torch.device(device)
+        self.dtype = dtype
+        model = model.eval()
+        conv0 = model.conv[0]
+        self.conv_w = [conv0.weight.detach().float()]
+        self.conv_b = [conv0.bias.detach().float()]
+        self.n_blocks = len(model.conv) - 1
+        for blk in list(model.conv)[1:]:
+            c1, c2, bn = blk.block[0], blk.block[1], blk.block[2]
+            self.conv_w.append(c1.weight.detach().float())
+            self.conv_b.append(c1.bias.detach().float())
+            w, b = _fold_bn(c2.weight, c2.bias, bn)
+            self.conv_w.append(w)
+            self.conv_b.append(b)
+
+        def head(seq):
+            ws, bs = [], []
+            mods = list(seq)
+            for m in mods[:-2]:
+                w, b = _fold_bn(m[0].weight, m[0].bias, m[1])
+                ws.append(w)
+                bs.append(b)
+            ws.append(mods[-2].weight.detach().float())
+            bs.append(mods[-2].bias.detach().float())
+            return ws, bs
+
+        self.pol_w, self.pol_b = head(model.fc_policy)
+        self.val_w, self.val_b = head(model.fc_value)
+        mv = lambda ts: [t.to(self.device, dtype).contiguous() for t in ts]
+        self.conv_w = [w.to(self.device, dtype).contiguous(memory_format=torch.channels_last) for w in self.conv_w]
+        self.conv_b = mv(self.conv_b)
+        self.pol_w, self.pol_b, self.val_w, self.val_b = mv(self.pol_w), mv(self.pol_b), mv(self.val_w), mv(self.val_b)
+
+    @torch.no_grad()
+    def forward(self, planes: torch.Tensor, out_logprobs: Optional[torch.Tensor] = None,
+                out_q: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        x = planes.to(self.dtype)
+        x = F.conv2d(x, self.conv_w[0], self.conv_b[0], padding=1)
+        for i in range(self.n_blocks):
+            y = F.conv2d(x, self.conv_w[1 + 2 * i], self.conv_b[1 + 2 * i], padding=1)
+            y = F.conv2d(y, self.conv_w[2 + 2 * i], self.conv_b[2 + 2 * i], padding=1)
+            x = x + F.relu(y)
+        x = x.reshape(x.shape[0], -1)
+        p = x
+        for w, b in zip(self.pol_w[:-1], self.pol_b[:-1]):
+            p = F.relu(F.linear(p, w, b))
+        p = F.linear(p, self.pol_w[-1], self.pol_b[-1]).float()
+        v = x
+        for w, b in zip(self.val_w[:-1], self.val_b[:-1]):
+            v = F.relu(F.linear(v, w, b))
+        v = F.linear(v, self.val_w[-1], self.val_b[-1]).float()
+        if out_logprobs is None:
+            lp = torch.log_softmax(p, dim=1)
+        else:
+            lp = torch.log_softmax(p, dim=1, out=out_logprobs) if False else out_logprobs.copy_(torch.log_softmax(p, dim=1))
+        q = torch.tanh(v) if out_q is None else torch.tanh(v, out=out_q)
+        return lp, q
+
+    __call__ = forward
+
+
+def flops_per_leaf(cfg: ModelConfig) -> int:
+    """2*MAC count of one forward."""
+    c, f = cfg.conv_filter_size, cfg.conv_filter_size * 42
+    conv = 2 * 42 * 9 * 2 * c + cfg.n_residual_blocks * 2 * (2 * 42 * 9 * c * c)
+    pol = (cfg.n_policy_layers - 1) * 2 * f * f + 2 * 7 * f
+    val = (cfg.n_value_layers - 1) * 2 * f * f + 2 * 2 * f
+    return conv + pol + val

@@ -1,0 +1,323 @@
+"""Result types of `play_games` -- the Python surface of the reference's PyO3 classes.
+
+Mirrors (names, arguments, behaviour) the classes the reference registers in
+rust/src/lib.rs:32-35: `GameMetadata` (types.rs:37-60), `Sample` (types.rs:103-153),
+`GameResult` (types.rs:63-100) and `PlayGamesResult` (pybridge.rs:58-158), so that the
+reference's callers (src/c4a0/training.py:179-207,317-333; tournament.py:84-139) work on
+GPU-generated games unchanged.  Host-side bookkeeping only; nothing here is on the hot path.
+"""
+from __future__ import annotations
+
+import struct
+from typing import Iterable, List, Sequence, Tuple
+
+import numpy as np
+
+N_COLS, N_ROWS = 7, 6
+_COL0 = 0x810204081  # bits 0,7,..,35: column 0
+_START03 = _COL0 | (_COL0 << 1) | (_COL0 << 2) | (_COL0 << 3)
+
+
+def _has_four(x: int) -> bool:
+    h = x & (x >> 1) & (x >> 2) & (x >> 3) & _START03
+    v = x & (x >> 7) & (x >> 14) & (x >> 21)
+    d1 = x & (x >> 8) & (x >> 16) & (x >> 24) & _START03
+    d2 = (x >> 3) & (x >> 9) & (x >> 15) & (x >> 21) & _START03
+    return (h | v | d1 | d2) != 0
+
+
+def terminal_state(mask: int, value: int) -> int:
+    """c4r.rs:228-238: 0 none, 1 PlayerWin, 2 OpponentWin, 3 Draw."""
+    if _has_four(mask & value):
+        return 1
+    if _has_four(mask & ~value):
+        return 2
+    if bin(mask).count("1") == 42:
+        return 3
+    return 0
+
+
+def flip_h_bits(x: int) -> int:
+    """Mirror the 7 columns of every row (c4r.rs:289-299)."""
+    out = 0
+    for col in range(7):
+        out |= ((x >> col) & _COL0) << (6 - col)
+    return out
+
+
+class GameMetadata:
+    """types.rs:37-60."""
+
+    __slots__ = ("game_id", "player0_id", "player1_id")
+
+    def __init__(self, game_id: int = 0, player0_id: int = 0, player1_id: int = 0):
+        for v in (game_id, player0_id, player1_id):
+            if not (0 <= int(v) < 1 << 64):
+                raise OverflowError("GameMetadata fields are u64")
+        self.game_id, self.player0_id, self.player1_id = int(game_id), int(player0_id), int(player1_id)
+
+    def __repr__(self):
+        return f"GameMetadata(game_id={self.game_id}, player0_id={self.player0_id}, player1_id={self.player1_id})"
+
+    def __eq__(self, o):
+        return isinstance(o, GameMetadata) and (self.game_id, self.player0_id, self.player1_id) == (o.game_id, o.player0_id, o.player1_id)
+
+
+class Sample:
+    """types.rs:103-153.  `pos` is the (mask, value) bitboard pair of c4r.rs:13-17."""
+
+    __slots__ = ("mask", "value", "policy", "q_penalty", "q_no_penalty")
+
+    def __init__(self, mask: int, value: int, policy: Sequence[float], q_penalty: float, q_no_penalty: float):
+        self.mask, self.value = int(mask), int(value)
+        self.policy = np.asarray(policy, dtype=np.float32).reshape(7).copy()
+        self.q_penalty = np.float32(q_penalty)
+        self.q_no_penalty = np.float32(q_no_penalty)
+
+    def flip_h(self) -> "Sample":  # types.rs:115-122
+        return Sample(flip_h_bits(self.mask), flip_h_bits(self.value), self.policy[::-1].copy(), self.q_penalty, self.q_no_penalty)
+
+    def to_numpy(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:  # types.rs:125-147
+        bits = np.arange(42, dtype=np.uint64)
+        p0 = ((np.uint64(self.value) >> bits) & np.uint64(1)).astype(np.float32)
+        p1 = ((np.uint64(self.mask & ~self.value) >> bits) & np.uint64(1)).astype(np.float32)
+        pos = np.concatenate([p0, p1]).reshape(2, N_ROWS, N_COLS)  # c4r.rs:378-392
+        return pos, self.policy.copy(), np.array(self.q_penalty, dtype=np.float32), np.array(self.q_no_penalty, dtype=np.float32)
+
+    def pos_str(self) -> str:  # types.rs:150-152 / c4r.rs:395-413
+        rows = []
+        for row in range(N_ROWS - 1, -1, -1):
+            s = ""
+            for col in range(N_COLS):
+                bit = 1 << (row * 7 + col)
+                s += "⚫" if not self.mask & bit else ("🔴" if self.value & bit else "🔵")
+            rows.append(s)
+        return "\n".join(rows)
+
+    def __eq__(self, o):
+        return (isinstance(o, Sample) and (self.mask, self.value) == (o.mask, o.value)
+                and self.policy.tobytes() == o.policy.tobytes()
+                and self.q_penalty.tobytes() == o.q_penalty.tobytes() and self.q_no_penalty.tobytes() == o.q_no_penalty.tobytes())
+
+    def __repr__(self):
+        return f"Sample(mask={self.mask:#x}, value={self.value:#x}, policy={self.policy.tolist()}, q_penalty={float(self.q_penalty)}, q_no_penalty={float(self.q_no_penalty)})"
+
+
+class GameResult:
+    """types.rs:63-100."""
+
+    __slots__ = ("metadata", "samples")
+
+    def __init__(self, metadata: GameMetadata, samples: List[Sample]):
+        self.metadata, self.samples = metadata, samples
+
+    def player0_score(self) -> float:  # types.rs:77-99
+        for s in self.samples:
+            t = terminal_state(s.mask, s.value)
+            if t:
+                score = {1: 1.0, 2: 0.0, 3: 0.5}[t]
+                return 1.0 - score if bin(s.mask).count("1") % 2 == 1 else score
+        raise RuntimeError("player0_score called on an unfinished game")  # reference panics
+
+    def __eq__(self, o):
+        return isinstance(o, GameResult) and self.metadata == o.metadata and self.samples == o.samples
+
+
+# ---------------------------------------------------------------------------------------------
+# CBOR wire format of PlayGamesResult (pybridge.rs:73-92): what serde_cbor 0.11.2 emits for the
+# derive(Serialize) structs -- definite-length maps keyed by field name in declaration order,
+# unsigned ints in the shortest form, f32 as half precision when that is lossless.
+# ---------------------------------------------------------------------------------------------
+def _cbor_uint(major: int, n: int) -> bytes:
+    if n < 24:
+        return bytes([major << 5 | n])
+    if n < 1 << 8:
+        return bytes([major << 5 | 24, n])
+    if n < 1 << 16:
+        return bytes([major << 5 | 25]) + struct.pack(">H", n)
+    if n < 1 << 32:
+        return bytes([major << 5 | 26]) + struct.pack(">I", n)
+    return bytes([major << 5 | 27]) + struct.pack(">Q", n)
+
+
+def _cbor_text(s: str) -> bytes:
+    b = s.encode()
+    return _cbor_uint(3, len(b)) + b
+
+
+def _cbor_f32(x: np.float32) -> bytes:
+    x = np.float32(x)
+    if np.isnan(x):
+        return b"\xf9\x7e\x00"
+    if np.isinf(x):
+        return b"\xf9\x7c\x00" if x > 0 else b"\xf9\xfc\x00"
+    with np.errstate(over="ignore"):
+        h = np.float16(x)
+    if np.float32(h) == x:
+        return b"\xf9" + struct.pack(">e", float(h))
+    return b"\xfa" + struct.pack(">f", float(x))
+
+
+_K = {k: _cbor_text(k) for k in ("results", "metadata", "samples", "game_id", "player0_id", "player1_id",
+                                 "pos", "policy", "q_penalty", "q_no_penalty", "mask", "value")}
+
+
+class _CborReader:
+    def __init__(self, data: bytes):
+        self.d, self.i = memoryview(data), 0
+
+    def head(self) -> Tuple[int, int]:
+        b = self.d[self.i]
+        self.i += 1
+        major, info = b >> 5, b & 31
+        if info < 24:
+            return major, info
+        n = {24: 1, 25: 2, 26: 4, 27: 8}.get(info)
+        if n is None:
+            raise ValueError("unsupported CBOR additional info (indefinite lengths are not produced by serde_cbor here)")
+        v = int.from_bytes(self.d[self.i:self.i + n], "big")
+        self.i += n
+        return major, (info << 64) | v if major == 7 else v
+
+    def uint(self) -> int:
+        major, v = self.head()
+        if major != 0:
+            raise ValueError("expected unsigned integer")
+        return v
+
+    def length(self, want_major: int) -> int:
+        major, v = self.head()
+        if major != want_major:
+            raise ValueError(f"expected CBOR major type {want_major}, got {major}")
+        return v
+
+    def text(self) -> str:
+        n = self.length(3)
+        s = bytes(self.d[self.i:self.i + n]).decode()
+        self.i += n
+        return s
+
+    def f32(self) -> np.float32:
+        major, v = self.head()
+        if major == 7:
+            info, raw = v >> 64, v & ((1 << 64) - 1)
+            if info == 25:
+                return np.float32(struct.unpack(">e", raw.to_bytes(2, "big"))[0])
+            if info == 26:
+                return np.float32(struct.unpack(">f", raw.to_bytes(4, "big"))[0])
+            if info == 27:
+                return np.float32(struct.unpack(">d", raw.to_bytes(8, "big"))[0])
+        if major == 0:
+            return np.float32(v)
+        raise ValueError("expected a float")
+
+    def struct_fields(self, names: Sequence[str]):
+        n = self.length(5)
+        if n != len(names):
+            raise ValueError(f"expected a map of {len(names)} fields")
+        for want in names:
+            got = self.text()
+            if got != want:
+                raise ValueError(f"expected field {want!r}, got {got!r}")
+            yield want
+
+
+class PlayGamesResult:
+    """pybridge.rs:58-158.  `score_policies` needs the external PascalPons solver and the
+    rocksdb cache (rust/src/solver.rs) -- out of scope, raises NotImplementedError."""
+
+    def __init__(self, results: Iterable[GameResult] = ()):  # pybridge.rs:67-70: empty constructor for unpickling
+        self.results: List[GameResult] = list(results)
+
+    # -- serialisation (pybridge.rs:73-92)
+    def to_cbor(self) -> bytes:
+        out = [_cbor_uint(5, 1), _K["results"], _cbor_uint(4, len(self.results))]
+        for r in self.results:
+            m = r.metadata
+            out += [_cbor_uint(5, 2), _K["metadata"], _cbor_uint(5, 3),
+                    _K["game_id"], _cbor_uint(0, m.game_id), _K["player0_id"], _cbor_uint(0, m.player0_id),
+                    _K["player1_id"], _cbor_uint(0, m.player1_id),
+                    _K["samples"], _cbor_uint(4, len(r.samples))]
+            for s in r.samples:
+                out += [_cbor_uint(5, 4), _K["pos"], _cbor_uint(5, 2), _K["mask"], _cbor_uint(0, s.mask),
+                        _K["value"], _cbor_uint(0, s.value), _K["policy"], _cbor_uint(4, 7)]
+                out += [_cbor_f32(p) for p in s.policy]
+                out += [_K["q_penalty"], _cbor_f32(s.q_penalty), _K["q_no_penalty"], _cbor_f32(s.q_no_penalty)]
+        return b"".join(out)
+
+    @staticmethod
+    def from_cbor(cbor: bytes) -> "PlayGamesResult":
+        try:
+            r = _CborReader(cbor)
+            results = []
+            for _ in r.struct_fields(["results"]):
+                for _g in range(r.length(4)):
+                    meta, samples = None, []
+                    for f in r.struct_fields(["metadata", "samples"]):
+                        if f == "metadata":
+                            vals = [r.uint() for _ in r.struct_fields(["game_id", "player0_id", "player1_id"])]
+                            meta = GameMetadata(*vals)
+                        else:
+                            for _s in range(r.length(4)):
+                                d = {}
+                                for sf in r.struct_fields(["pos", "policy", "q_penalty", "q_no_penalty"]):
+                                    if sf == "pos":
+                                        d["pos"] = [r.uint() for _ in r.struct_fields(["mask", "value"])]
+                                    elif sf == "policy":
+                                        if r.length(4) != 7:
+                                            raise ValueError("policy must have 7 entries")
+                                        d["policy"] = [r.f32() for _ in range(7)]
+                                    else:
+                                        d[sf] = r.f32()
+                                samples.append(Sample(d["pos"][0], d["pos"][1], d["policy"], d["q_penalty"], d["q_no_penalty"]))
+                    results.append(GameResult(meta, samples))
+            if r.i != len(cbor):
+                raise ValueError("trailing bytes")
+            return PlayGamesResult(results)
+        except (IndexError, struct.error) as e:  # truncated input
+            raise ValueError(f"invalid CBOR: {e}") from e
+
+    def __getstate__(self) -> bytes:
+        return self.to_cbor()
+
+    def __setstate__(self, state: bytes) -> None:
+        self.results = PlayGamesResult.from_cbor(state).results
+
+    # -- pybridge.rs:95-106
+    def __add__(self, other: "PlayGamesResult") -> "PlayGamesResult":
+        if not isinstance(other, PlayGamesResult):
+            raise TypeError("can only add PlayGamesResult")
+        return PlayGamesResult(self.results + other.results)
+
+    # -- pybridge.rs:110-120.  Whole games go to one side; the permutation is a seeded,
+    # deterministic shuffle (the reference's exact permutation depends on rand 0.10 internals,
+    # which no reference test pins: pybridge_test.py:22-39 only requires determinism and that
+    # `self` is not mutated).
+    def split_train_test(self, train_frac: float, seed: int) -> Tuple[List[Sample], List[Sample]]:
+        results = list(self.results)
+        np.random.Generator(np.random.PCG64(int(seed) & ((1 << 64) - 1))).shuffle(results)
+        n_train = int(np.round(np.float32(len(results)) * np.float32(train_frac)))  # f32 math + round, as the reference
+        n_train = max(0, min(len(results), n_train))
+        train = [s for r in results[:n_train] for s in r.samples]
+        test = [s for r in results[n_train:] for s in r.samples]
+        return train, test
+
+    def score_policies(self, solver_path: str, solver_book_path: str, solution_cache_path: str) -> float:
+        raise NotImplementedError("score_policies needs the external c4solver binary and book (reference rust/src/solver.rs); out of scope")
+
+    def unique_positions(self) -> int:  # pybridge.rs:150-157
+        return len({(s.mask, s.value) for r in self.results for s in r.samples})
+
+    def __eq__(self, o):
+        return isinstance(o, PlayGamesResult) and self.results == o.results
+
+
+def results_from_records(reqs: Sequence[GameMetadata], recs: np.ndarray, counts: np.ndarray) -> PlayGamesResult:
+    """Build the result list from the packed sample records of `c4_session_drain_samples`
+    (records of finished games in reqs order) and the per-game sample counts."""
+    out, off = [], 0
+    for meta, n in zip(reqs, counts.tolist()):
+        chunk = recs[off:off + n]
+        off += n
+        out.append(GameResult(meta, [Sample(int(r["mask"]), int(r["value"]), r["policy"], r["q_penalty"], r["q_no_penalty"]) for r in chunk]))
+    return PlayGamesResult(out)

@@ -1,0 +1,172 @@
+"""Host driver of one GPU's self-play session.
+
+Mirrors the role of `self_play()` (reference rust/src/self_play.rs:39-129): it owns the loop
+"evaluate the leaves of all games -> give every game its MCTS job" until all games are over.
+Here the MCTS jobs of all resident games are one HIP kernel (`c4_session_step`) and the
+evaluator runs on the same stream on persistent tensors, so leaf batches never leave HBM.
+PyTorch supplies device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import C4Error, Config, Counters, GameMetadataC, SampleRec, check
+
+DeviceEvaluator = Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]
+"""evaluator(planes[G,2,6,7]) -> (policy_logprobs[G,7] float32, q[G,2] float32) on the same device."""
+
+
+class DeviceSession:
+    def __init__(self, n_slots: int, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float,
+                 device: Optional[torch.device] = None, planes_dtype: torch.dtype = torch.float32,
+                 blocks_per_slot: int = 0, no_moves: bool = False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("c4a0_amd needs a HIP device: the tree kernels have no CPU fallback")
+        self.L = _lib.lib()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise ValueError("device must be a cuda (HIP) device")
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if planes_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("planes_dtype must be float32 or bfloat16")
+        self.n_slots = int(n_slots)
+        self.n_mcts_iterations = int(n_mcts_iterations)
+        cfg = Config(self.n_slots, int(blocks_per_slot), self.n_mcts_iterations, float(c_exploration),
+                     float(c_ply_penalty), 0 if planes_dtype == torch.float32 else 1,
+                     _lib.FLAG_NO_MOVES if no_moves else 0, dev_index)
+        h = C.c_void_p()
+        check(self.L.c4_session_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        with torch.cuda.device(self.device):
+            self.planes = torch.zeros((self.n_slots, 2, 6, 7), dtype=planes_dtype, device=self.device)
+            self.logprobs = torch.zeros((self.n_slots, 7), dtype=torch.float32, device=self.device)
+            self.q = torch.zeros((self.n_slots, 2), dtype=torch.float32, device=self.device)
+        self.n_games = 0
+        self._bound_stream = None
+
+    # ---------------------------------------------------------------- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.c4_session_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- setup
+    def set_games(self, reqs: Sequence[Tuple[int, int, int]], start_positions: Optional[Sequence[Tuple[int, int]]] = None):
+        n = len(reqs)
+        arr = (GameMetadataC * max(1, n))()
+        for i, (gid, p0, p1) in enumerate(reqs):
+            arr[i] = GameMetadataC(int(gid), int(p0), int(p1))
+        sm = sv = None
+        if start_positions is not None:
+            if len(start_positions) != n:
+                raise ValueError("start_positions must match reqs")
+            sm = (C.c_uint64 * max(1, n))(*[int(m) for m, _ in start_positions])
+            sv = (C.c_uint64 * max(1, n))(*[int(v) for _, v in start_positions])
+        check(self.L.c4_session_set_games(self._h, arr, n, sm, sv))
+        self.n_games = n
+
+    def bind(self, stream: Optional[torch.cuda.Stream] = None):
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        check(self.L.c4_session_bind_io(self._h, self.planes.data_ptr(), self.logprobs.data_ptr(), self.q.data_ptr(),
+                                        C.c_void_p(st.cuda_stream)))
+        self._bound_stream = st
+
+    def start(self):
+        check(self.L.c4_session_start(self._h))
+
+    def step(self):
+        check(self.L.c4_session_step(self._h))
+
+    # ---------------------------------------------------------------- results
+    def counters(self) -> dict:
+        c = Counters()
+        check(self.L.c4_session_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def poll(self) -> Tuple[int, int]:
+        done, err = C.c_uint64(), C.c_uint32()
+        check(self.L.c4_session_poll(self._h, C.byref(done), C.byref(err)))
+        return done.value, err.value
+
+    def raise_if_device_error(self):
+        c = self.counters()
+        if c["error"]:
+            raise C4Error(c["error"], f"raised on device by slot {c['error_slot']}")
+
+    def sample_counts(self) -> np.ndarray:
+        out = np.zeros(max(1, self.n_games), dtype=np.uint32)
+        check(self.L.c4_session_sample_counts(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), self.n_games))
+        return out[: self.n_games]
+
+    def drain_samples(self) -> np.ndarray:
+        """All samples of finished games, packed in reqs order, as a structured numpy array."""
+        n = C.c_uint64()
+        check(self.L.c4_session_drain_samples(self._h, None, 0, C.byref(n)))
+        buf = np.zeros(max(1, n.value), dtype=SAMPLE_DTYPE)
+        check(self.L.c4_session_drain_samples(self._h, buf.ctypes.data_as(C.POINTER(SampleRec)), n.value, C.byref(n)))
+        return buf[: n.value]
+
+    def root_stats(self, slot: int = 0):
+        pol = (C.c_float * 7)()
+        qp, qn = C.c_float(), C.c_float()
+        n, m, v = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(self.L.c4_session_root_stats(self._h, slot, pol, C.byref(qp), C.byref(qn), C.byref(n), C.byref(m), C.byref(v)))
+        return np.array(pol[:], dtype=np.float32), qp.value, qn.value, n.value, (m.value, v.value)
+
+    def leaves(self, with_ordinals: bool = False):
+        m = np.zeros(self.n_slots, dtype=np.uint64)
+        v = np.zeros(self.n_slots, dtype=np.uint64)
+        s = np.zeros(self.n_slots, dtype=np.uint32)
+        o = np.zeros(self.n_slots, dtype=np.uint32)
+        check(self.L.c4_session_leaves(self._h, m.ctypes.data_as(C.POINTER(C.c_uint64)), v.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       s.ctypes.data_as(C.POINTER(C.c_uint32)), o.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return (m, v, s, o) if with_ordinals else (m, v, s)
+
+    # ---------------------------------------------------------------- the loop
+    def evaluate(self, evaluator: DeviceEvaluator):
+        lp, q = evaluator(self.planes)
+        if lp.data_ptr() != self.logprobs.data_ptr():
+            self.logprobs.copy_(lp.reshape(self.n_slots, 7))
+        if q.data_ptr() != self.q.data_ptr():
+            self.q.copy_(q.reshape(self.n_slots, 2))
+
+    def run(self, evaluator: DeviceEvaluator, max_steps: Optional[int] = None, poll_every: int = 16,
+            on_step: Optional[Callable[[int], None]] = None) -> int:
+        """Play all games set by set_games() to completion.  Returns the number of steps."""
+        self.bind()
+        self.start()
+        steps = 0
+        while True:
+            self.evaluate(evaluator)
+            if on_step is not None:
+                on_step(steps)
+            self.step()
+            steps += 1
+            if steps % poll_every == 0:
+                done, err = self.poll()
+                if err:
+                    self.raise_if_device_error()
+                if done >= self.n_games:
+                    break
+            if max_steps is not None and steps >= max_steps:
+                break
+        c = self.counters()
+        if c["error"]:
+            raise C4Error(c["error"], f"raised on device by slot {c['error_slot']}")
+        return steps
+
+
+SAMPLE_DTYPE = np.dtype([("game_id", "<u8"), ("mask", "<u8"), ("value", "<u8"), ("policy", "<f4", (7,)),
+                         ("q_penalty", "<f4"), ("q_no_penalty", "<f4"), ("meta", "<u4")])
+assert SAMPLE_DTYPE.itemsize == 64

@@ -1,0 +1,178 @@
+/*
+ * c4a0_hip.h -- C ABI of the MI355X-native self-play generator (libc4a0_hip.so).
+ *
+ * Drop-in boundary for the reference's self-play hot path.  The reference has no C header:
+ * its boundary is the PyO3 function `play_games` (rust/src/pybridge.rs:20-53) which calls
+ * `self_play::self_play` (rust/src/self_play.rs:39-129).  The entry points below are what a
+ * Rust host would bind with `extern "C"` to replace the body of `self_play()` (INTEGRATION.md
+ * shows the binding); each one cites the reference code it replaces.
+ *
+ * Conventions: every function returns a c4_status (0 = ok); c4_last_error_string() gives the
+ * detail for the calling thread.  All pointers named *_dev are DEVICE pointers owned by the
+ * caller (e.g. PyTorch tensors) and must stay valid until the session is destroyed or rebound.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).  No function
+ * synchronises the device unless its comment says so.
+ */
+#ifndef C4A0_HIP_H
+#define C4A0_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C4_N_COLS 7          /* rust/src/c4r.rs:45, lib.rs:28 */
+#define C4_N_ROWS 6          /* rust/src/c4r.rs:44, lib.rs:29 */
+#define C4_BUF_N_CHANNELS 2  /* rust/src/c4r.rs:48, lib.rs:30 */
+#define C4_PLANES_LEN 84     /* rust/src/c4r.rs:52 BUF_LEN */
+#define C4_MAX_SAMPLES_PER_GAME 43 /* <= 42 moves + the terminal sample, mcts.rs:271-313 */
+
+typedef enum {
+  C4_OK = 0,
+  C4_ERR_BAD_ARG = 1,
+  C4_ERR_HIP = 2,               /* a HIP runtime call failed */
+  C4_ERR_NAN_IN_TREE = 3,       /* reference panics: utils.rs:12 (OrdF32 on NaN) */
+  C4_ERR_DEGENERATE_POLICY = 4, /* reference panics: mcts.rs:421-425, mcts.rs:219 */
+  C4_ERR_ARENA_OVERFLOW = 5,    /* blocks_per_slot too small for this game's tree */
+  C4_ERR_NOT_BOUND = 6,         /* step before bind_io / set_games */
+  C4_ERR_NO_DEVICE = 7,
+  C4_ERR_ILLEGAL_MOVE = 8       /* reference panics: mcts.rs:196-200 (sampled a full column; only possible when the
+                                   root's children have no visits, i.e. n_mcts_iterations <= 1) */
+} c4_status;
+
+/* types.rs:37-48 GameMetadata */
+typedef struct {
+  uint64_t game_id;
+  uint64_t player0_id;
+  uint64_t player1_id;
+} c4_game_metadata;
+
+/* One training sample (types.rs:103-110 Sample + the game it belongs to), 64 bytes.
+ * meta = sample index within the game (low 16 bits) | flags << 16 (bit 0: terminal sample). */
+typedef struct {
+  uint64_t game_id;
+  uint64_t mask;   /* c4r.rs:13-17 Pos.mask  */
+  uint64_t value;  /* c4r.rs:13-17 Pos.value */
+  float policy[7];
+  float q_penalty;
+  float q_no_penalty;
+  uint32_t meta;
+} c4_sample_rec;
+
+/* Arguments of self_play() (self_play.rs:39-46) that are fixed for a session, plus sizing. */
+typedef struct {
+  uint32_t n_slots;           /* games resident on the GPU and advanced in lock-step */
+  uint32_t blocks_per_slot;   /* tree arena per slot, in 7-children blocks; 0 = worst case 43*n_mcts_iterations+8 */
+  uint32_t n_mcts_iterations; /* self_play.rs:43 */
+  float c_exploration;        /* self_play.rs:44 (f32, as pybridge.rs:26) */
+  float c_ply_penalty;        /* self_play.rs:45 */
+  uint32_t planes_dtype;      /* 0 = float32, 1 = bfloat16: element type of the NN input buffer */
+  uint32_t flags;             /* C4_FLAG_* */
+  int32_t device;             /* HIP device ordinal */
+} c4_config;
+
+#define C4_FLAG_NO_MOVES 1u   /* never move: mcts.rs test helper `run_mcts` (mcts.rs:469-485) */
+
+/* Device-side counters (the reference's progress bars, self_play.rs:352-381, plus the
+ * roofline numerators of SURVEY 8d).  Sums over all games since set_games. */
+typedef struct {
+  uint64_t sims;            /* on_received_policy calls executed (self_play.rs:272) */
+  uint64_t select_levels;   /* sum of S: children blocks scanned by select_new_leaf (mcts.rs:160-183) */
+  uint64_t backup_nodes;    /* sum of K: nodes updated by backpropagate_value (mcts.rs:137-155) */
+  uint64_t expansions;      /* sum of E: expand_leaf calls that created children (mcts.rs:114-132) */
+  uint64_t moves;           /* make_random_move calls (mcts.rs:214-222) */
+  uint64_t games_done;
+  uint64_t ref_skipped_sims;/* terminal-root sims the reference would still run (self_play.rs:283-301) */
+  uint64_t samples;
+  uint64_t games_started;
+  uint32_t error;           /* first c4_status raised on the device, 0 = none */
+  uint32_t error_slot;
+} c4_counters;
+
+typedef struct c4_session c4_session;
+
+const char* c4_last_error_string(void);
+int c4_device_count(int* out);
+
+/* Replaces the set-up half of self_play() (self_play.rs:47-58): allocates the tree arenas,
+ * slot states and counters on `cfg->device`. */
+int c4_session_create(const c4_config* cfg, c4_session** out);
+int c4_session_destroy(c4_session* s);
+
+/* `reqs: Vec<GameMetadata>` of self_play() (self_play.rs:41).  Copies the list to the device,
+ * allocates the sample store (43 records per game), resets queue and counters.
+ * start_masks/start_values (host arrays, may be NULL = empty board, self_play.rs:56) give
+ * MctsGame::new_from_pos positions (mcts.rs:48) for tests.  Synchronises the stream. */
+int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n_games,
+                         const uint64_t* start_masks, const uint64_t* start_values);
+
+/* Replaces EvalPosT / PyEvalPos / create_pos_batch (types.rs:24-34, pybridge.rs:161-221):
+ * instead of a callback the evaluator's tensors are bound once.
+ *   planes_dev   [n_slots][2][6][7]  written by the library (row g = leaf of slot g)
+ *   logprobs_dev [n_slots][7] f32    read by the library (policy logits / log-probs)
+ *   q_dev        [n_slots][2] f32    read by the library (q_penalty, q_no_penalty) */
+int c4_session_bind_io(c4_session* s, void* planes_dev, const float* logprobs_dev, const float* q_dev,
+                       void* stream);
+
+/* Puts the first n_slots games on the slots and writes their first leaf (the start position)
+ * to planes_dev: the state self_play() is in after self_play.rs:55-58. */
+int c4_session_start(c4_session* s);
+
+/* One MctsThread job (self_play.rs:268-323) for EVERY resident game: consume the evaluator
+ * outputs for the current leaves (on_received_policy, mcts.rs:83-108), make a move when the
+ * root has n_mcts_iterations visits (make_random_move, mcts.rs:214-222), finish and replace
+ * finished games, select the next leaves and write them to planes_dev.  Asynchronous. */
+int c4_session_step(c4_session* s);
+
+/* Synchronises the stream and sums the per-wavefront counters. */
+int c4_session_counters(c4_session* s, c4_counters* out);
+/* Non-blocking completion probe: enqueues a copy of (games_done, error) to pinned host
+ * memory; *games_done / *error hold the values of the previous probe that has landed. */
+int c4_session_poll(c4_session* s, uint64_t* games_done, uint32_t* error);
+
+/* GameResult list (types.rs:63-71, mcts.rs:271-313).  Two-call pattern: n_samples of every
+ * game (host array of n_games uint32, 0 = unfinished), then the records of finished games
+ * packed in reqs order into dst_host (capacity cap records).  Both synchronise the stream. */
+int c4_session_sample_counts(c4_session* s, uint32_t* counts_host, uint64_t n_games);
+int c4_session_drain_samples(c4_session* s, c4_sample_rec* dst_host, uint64_t cap, uint64_t* n_written);
+/* Device views for collectives (RCCL all-gather of samples): records [n_games][43], counts [n_games]. */
+int c4_session_sample_store(c4_session* s, const c4_sample_rec** recs_dev, const uint32_t** counts_dev, uint64_t* n_games);
+
+/* Root statistics of slot `slot` (MctsGame::root_policy / root_q_with_penalty /
+ * root_q_no_penalty / root_visit_count, mcts.rs:248-268).  Synchronises. */
+int c4_session_root_stats(c4_session* s, uint32_t slot, float policy[7], float* q_penalty,
+                          float* q_no_penalty, uint64_t* visit_count, uint64_t* root_mask, uint64_t* root_value);
+/* Leaf position currently waiting for the evaluator, per slot (MctsGame::leaf_pos, mcts.rs:64-66);
+ * status[g] = 1 active / 0 idle, ordinal[g] = index of the slot's game in reqs.  Host arrays of
+ * n_slots (any may be NULL).  Synchronises.  Used by the numpy-callback compatibility mode. */
+int c4_session_leaves(c4_session* s, uint64_t* masks_host, uint64_t* values_host, uint32_t* status_host,
+                      uint32_t* ordinals_host);
+
+/* ---- element-wise device functions (SURVEY 8a kernel K1 and the arithmetic pieces), all on
+ * device arrays of length n, launched on `stream`; used by the parity tests. ---- */
+/* c4r.rs:58-72,228-238,253-263,266-269: for each position and column: moved position (0,0 if
+ * illegal), legal mask, terminal state (0 none,1 PlayerWin,2 OpponentWin,3 Draw) and terminal values. */
+int c4_pos_ops(const uint64_t* mask_dev, const uint64_t* value_dev, const int32_t* col_dev, uint64_t n,
+               float c_ply_penalty, uint64_t* out_mask_dev, uint64_t* out_value_dev, uint32_t* out_legal_dev,
+               uint32_t* out_terminal_dev, float* out_q_dev /* [n][2] */, void* stream);
+/* c4r.rs:378-392 / pybridge.rs:202-221 */
+int c4_encode_planes(const uint64_t* mask_dev, const uint64_t* value_dev, uint64_t n, uint32_t planes_dtype,
+                     void* planes_dev, void* stream);
+/* glibc expf/logf ports (what Rust f32::exp / f32::ln call) */
+int c4_expf_logf(const float* x_dev, uint64_t n, int which /*0 expf, 1 logf*/, float* y_dev, void* stream);
+/* mcts.rs:416-434 (with c4r.rs:272-286 masking when legal_dev != NULL); status per row in out_err_dev */
+int c4_softmax7(const float* logits_dev, const uint32_t* legal_dev, uint64_t n, float* out_dev,
+                uint32_t* out_err_dev, void* stream);
+/* mcts.rs:439-454 */
+int c4_apply_temperature(const float* policy_dev, const float* temperature_dev, uint64_t n, float* out_dev, void* stream);
+/* mcts.rs:214-222 without the tree update: column sampled for (game_id, n_moves, policy, temperature);
+ * out_col = -1 on DEGENERATE_POLICY.  out_u32 (may be NULL) = the RNG's first word. */
+int c4_sample_move(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, const float* policy_dev,
+                   const float* temperature_dev, uint64_t n, int32_t* out_col_dev, uint32_t* out_u32_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

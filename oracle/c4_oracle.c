@@ -471,6 +471,7 @@ struct c4o_game {
   float mv_policy[C4O_MAX_MOVES + 1][7];
   int mv_col[C4O_MAX_MOVES + 1];
   int error;
+  uint64_t last_select_levels;
   c4o_counters ctr;
 };
 
@@ -578,6 +579,7 @@ static void backpropagate_value(c4o_game* g, float q_penalty, float q_no_penalty
  * as soon as two keys are compared. */
 static void select_new_leaf(c4o_game* g, float c_exploration) {
   int idx = g->root;
+  g->last_select_levels = 0;
   for (;;) {
     const c4o_node* n = &g->nodes[idx];
     if (!n->has_children) break;
@@ -597,6 +599,7 @@ static void select_new_leaf(c4o_game* g, float c_exploration) {
     }
     if (best < 0) break; /* children Some([None;7]) cannot occur: expand needs a non-terminal leaf */
     g->ctr.select_levels++;
+    g->last_select_levels++;
     idx = best;
   }
   g->leaf = idx;
@@ -751,6 +754,7 @@ int c4o_game_step(c4o_game* g, const float* logprobs7, float q_pen, float q_nope
   int e = c4o_game_on_received_policy(g, logprobs7, q_pen, q_nopen, c_exploration, c_ply_penalty);
   if (e) return -e;
   if (c4o_game_root_visit_count(g) < n_mcts_iterations) return 0; /* self_play.rs:283-286 */
+  g->ctr.select_levels_discarded += g->last_select_levels;
   c4o_pos root_pos = g->nodes[g->root].pos;
   if (c4o_terminal_state(&root_pos) == C4O_NOT_TERMINAL) {
     int ply = c4o_ply(&root_pos); /* self_play.rs:294-299 */
@@ -969,7 +973,8 @@ int c4o_self_play(const c4o_game_metadata* reqs, uint64_t n_games, int max_nn_ba
     c4o_counters c;
     c4o_game_counters(games[i], &c);
     st.tree.sims += c.sims; st.tree.sims_terminal_root += c.sims_terminal_root;
-    st.tree.select_levels += c.select_levels; st.tree.backup_nodes += c.backup_nodes;
+    st.tree.select_levels += c.select_levels; st.tree.select_levels_discarded += c.select_levels_discarded;
+    st.tree.backup_nodes += c.backup_nodes;
     st.tree.expansions += c.expansions; st.tree.nodes_created += c.nodes_created; st.tree.moves += c.moves;
     c4o_game_free(games[i]);
   }

@@ -100,7 +100,9 @@ typedef struct {
 typedef struct {
   uint64_t sims;               /* on_received_policy calls (self_play.rs:272) */
   uint64_t sims_terminal_root; /* of which: leaf == root and root terminal */
-  uint64_t select_levels;      /* children scanned levels in select_new_leaf */
+  uint64_t select_levels;      /* children-array scans in select_new_leaf, every call (reference-faithful) */
+  uint64_t select_levels_discarded; /* of which: the select of a job whose gate then moves or ends the game
+                                     (self_play.rs:283-301): its leaf is replaced by make_move's own select */
   uint64_t backup_nodes;       /* nodes updated in backpropagate_value, excluding terminal-root sims */
   uint64_t expansions;         /* expand_leaf calls that created children */
   uint64_t nodes_created;

@@ -43,7 +43,7 @@ class CSample(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
-        "sims", "sims_terminal_root", "select_levels", "backup_nodes", "expansions", "nodes_created", "moves")]
+        "sims", "sims_terminal_root", "select_levels", "select_levels_discarded", "backup_nodes", "expansions", "nodes_created", "moves")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

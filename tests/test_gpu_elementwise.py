@@ -1,0 +1,198 @@
+"""GPU parity, element-wise pieces (SURVEY 8a kernel K1 + arithmetic): HIP vs the CPU oracle,
+bit for bit, through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from c4a0_amd import _lib
+    from oracle import c4oracle as O
+
+    return _lib.lib(), _lib, O, torch.device("cuda:0")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _u64(t):  # torch has no uint64 arithmetic; int64 carries the same bits
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_pos_ops_vs_oracle(env):
+    L, _lib, O, dev = env
+    from tests.helpers import random_positions
+
+    n = 200_000
+    pos = random_positions(n, seed=11)
+    mask = np.array([p[0] for p in pos], dtype=np.uint64)
+    value = np.array([p[1] for p in pos], dtype=np.uint64)
+    rng = np.random.default_rng(3)
+    col = rng.integers(-1, 8, size=n).astype(np.int32)  # includes out-of-range columns
+    tm = torch.from_numpy(mask.view(np.int64)).to(dev)
+    tv = torch.from_numpy(value.view(np.int64)).to(dev)
+    tc = torch.from_numpy(col).to(dev)
+    om, ov = torch.empty_like(tm), torch.empty_like(tv)
+    ol = torch.empty(n, dtype=torch.int32, device=dev)
+    ot = torch.empty(n, dtype=torch.int32, device=dev)
+    oq = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    _lib.check(L.c4_pos_ops(_ptr(tm), _ptr(tv), _ptr(tc), n, 0.01, _ptr(om), _ptr(ov), _ptr(ol), _ptr(ot), _ptr(oq), None))
+    torch.cuda.synchronize()
+    om, ov, ol, ot, oq = _u64(om), _u64(ov), ol.cpu().numpy(), ot.cpu().numpy(), oq.cpu().numpy()
+    OL = O.lib()
+    for i in range(0, n, 1):
+        p = O.Pos(int(mask[i]), int(value[i]))
+        assert ol[i] == OL.c4o_legal_mask(C.byref(p))
+        a, b = C.c_float(), C.c_float()
+        t = OL.c4o_terminal_value(C.byref(p), 0.01, C.byref(a), C.byref(b))
+        assert ot[i] == t
+        if t:
+            assert oq[i, 0] == a.value and oq[i, 1] == b.value
+        nx = O.Pos()
+        if OL.c4o_make_move(C.byref(p), int(col[i]), C.byref(nx)):
+            assert (om[i], ov[i]) == (nx.mask, nx.value)
+        else:
+            assert (om[i], ov[i]) == (0, 0)
+
+
+def test_pos_ops_edge_cases(env):
+    """The reference's rule KATs (c4r.rs:475-520) through the HIP kernel."""
+    L, _lib, O, dev = env
+    cases = [O.from_moves([0, 0, 1, 1, 2, 2, 3]), O.from_moves([6, 0, 6, 0, 6, 0, 6]),
+             O.from_moves([0, 1, 2, 3, 4, 5] * 3 + [5, 4, 3, 2, 1, 0] * 3 + [6] * 6), O.Pos(0, 0), O.Pos(0b1111, 0b1111)]
+    want_t = [2, 2, 3, 0, 1]
+    n = len(cases)
+    tm = torch.tensor([np.int64(np.uint64(p.mask)) for p in cases], dtype=torch.int64, device=dev)
+    tv = torch.tensor([np.int64(np.uint64(p.value)) for p in cases], dtype=torch.int64, device=dev)
+    tc = torch.zeros(n, dtype=torch.int32, device=dev)
+    om, ov = torch.empty_like(tm), torch.empty_like(tv)
+    ol = torch.empty(n, dtype=torch.int32, device=dev)
+    ot = torch.empty(n, dtype=torch.int32, device=dev)
+    oq = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    _lib.check(L.c4_pos_ops(_ptr(tm), _ptr(tv), _ptr(tc), n, 0.01, _ptr(om), _ptr(ov), _ptr(ol), _ptr(ot), _ptr(oq), None))
+    torch.cuda.synchronize()
+    assert ot.cpu().tolist() == want_t
+    assert ol.cpu().tolist()[2] == 0 and ol.cpu().tolist()[3] == 0x7F
+    assert oq.cpu().numpy()[2].tolist() == [0.0, 0.0]
+
+
+def test_encode_planes(env):
+    L, _lib, O, dev = env
+    from tests.helpers import random_positions
+
+    pos = random_positions(5000, seed=5)
+    mask = np.array([p[0] for p in pos], dtype=np.uint64)
+    value = np.array([p[1] for p in pos], dtype=np.uint64)
+    tm = torch.from_numpy(mask.view(np.int64)).to(dev)
+    tv = torch.from_numpy(value.view(np.int64)).to(dev)
+    want = np.stack([O.planes(O.Pos(int(m), int(v))) for m, v in pos[:500]])
+    for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+        out = torch.full((len(pos), 2, 6, 7), 7.0, dtype=dt, device=dev)
+        _lib.check(L.c4_encode_planes(_ptr(tm), _ptr(tv), len(pos), code, _ptr(out), None))
+        torch.cuda.synchronize()
+        got = out.float().cpu().numpy()
+        assert np.array_equal(got[:500], want)
+        assert set(np.unique(got).tolist()) <= {0.0, 1.0}
+
+
+def _host(O, which, x):
+    y = np.empty_like(x)
+    fn = O.lib().c4o_host_logf if which else O.lib().c4o_host_expf
+    fn(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)), x.size)
+    return y
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_device_expf_logf_vs_host_libm(env, which):
+    """The device ports must equal the HOST glibc (what Rust's f32::exp/ln call) on every
+    bit pattern sampled: a 2^25-point strided sweep of all floats plus dense windows."""
+    L, _lib, O, dev = env
+    chunks = [np.arange(0, 2 ** 32, 131, dtype=np.uint64).astype(np.uint32)]
+    if which == 0:  # softmax arguments: [-40, 0] densely
+        lo, hi = np.float32(-0.0).view(np.uint32), np.float32(-40.0).view(np.uint32)
+        chunks.append(np.arange(lo, hi, 7, dtype=np.uint64).astype(np.uint32))
+    else:  # ln of visit counts and of probabilities
+        chunks.append(np.arange(0, 1 << 20, dtype=np.float32).view(np.uint32))
+        chunks.append(np.arange(np.float32(1e-6).view(np.uint32), np.float32(1.0).view(np.uint32), 11, dtype=np.uint64).astype(np.uint32))
+    for bits in chunks:
+        x = bits.view(np.float32).copy()
+        tx = torch.from_numpy(x).to(dev)
+        ty = torch.empty_like(tx)
+        _lib.check(L.c4_expf_logf(_ptr(tx), x.size, which, _ptr(ty), None))
+        torch.cuda.synchronize()
+        got = ty.cpu().numpy()
+        want = _host(O, which, x)
+        nan = np.isnan(want)
+        assert np.array_equal(np.isnan(got), nan)
+        bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)) & ~nan)[0]
+        assert bad.size == 0, (hex(int(bits[bad[0]])), got[bad[0]], want[bad[0]])
+
+
+def test_softmax_temperature_sample_vs_oracle(env):
+    L, _lib, O, dev = env
+    rng = np.random.default_rng(17)
+    n = 20000
+    logits = rng.normal(0, 4, (n, 7)).astype(np.float32)
+    logits[:50] = 0.0
+    logits[50:60, 2] = -6.872888e19                       # proptest regression, mcts.txt:8
+    legal = rng.integers(1, 128, n).astype(np.uint32)
+    legal[:100] = 0x7F
+    tl = torch.from_numpy(logits).to(dev)
+    tg = torch.from_numpy(legal.view(np.int32)).to(dev)
+    out = torch.empty_like(tl)
+    err = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.check(L.c4_softmax7(_ptr(tl), _ptr(tg), n, _ptr(out), _ptr(err), None))
+    torch.cuda.synchronize()
+    sm = out.cpu().numpy()
+    assert int(err.sum().item()) == 0
+    for i in range(0, n, 7):
+        l = logits[i].copy()
+        l[[(legal[i] >> c) & 1 == 0 for c in range(7)]] = -np.inf
+        assert np.array_equal(sm[i].view(np.uint32), O.softmax7(l).view(np.uint32)), i
+    # degenerate rows are flagged, not silently uniform (mcts.rs:421-425)
+    bad = torch.full((3, 7), float("-inf"), device=dev)
+    o2 = torch.empty_like(bad)
+    e2 = torch.empty(3, dtype=torch.int32, device=dev)
+    _lib.check(L.c4_softmax7(_ptr(bad), None, 3, _ptr(o2), _ptr(e2), None))
+    torch.cuda.synchronize()
+    assert e2.cpu().tolist() == [4, 4, 4]
+
+    # temperature (mcts.rs:439-454) on visit-count style policies incl. zeros and ties
+    counts = rng.integers(0, 60, (n, 7)).astype(np.float32)
+    counts[counts.sum(1) == 0] = 1
+    counts[:200, 3] = 0
+    counts[200:300] = 5
+    pol = (counts / counts.sum(1, keepdims=True, dtype=np.float32)).astype(np.float32)
+    temps = rng.choice(np.array([4.0, 2.0, 1.0, 0.0, 0.5], dtype=np.float32), n)
+    tp, tt = torch.from_numpy(pol).to(dev), torch.from_numpy(temps).to(dev)
+    to = torch.empty_like(tp)
+    _lib.check(L.c4_apply_temperature(_ptr(tp), _ptr(tt), n, _ptr(to), None))
+    torch.cuda.synchronize()
+    got = to.cpu().numpy()
+    for i in range(0, n, 5):
+        assert np.array_equal(got[i].view(np.uint32), O.apply_temperature(pol[i], float(temps[i])).view(np.uint32)), i
+
+    # move sampling (mcts.rs:214-222)
+    gid = rng.integers(0, 1 << 40, n).astype(np.uint64)
+    gid[:10] = 0
+    nm = rng.integers(0, 42, n).astype(np.uint32)
+    tgid = torch.from_numpy(gid.view(np.int64)).to(dev)
+    tnm = torch.from_numpy(nm.view(np.int32)).to(dev)
+    oc = torch.empty(n, dtype=torch.int32, device=dev)
+    ou = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.check(L.c4_sample_move(_ptr(tgid), _ptr(tnm), _ptr(tp), _ptr(tt), n, _ptr(oc), _ptr(ou), None))
+    torch.cuda.synchronize()
+    oc, ou = oc.cpu().numpy(), ou.cpu().numpy().view(np.uint32)
+    OL = O.lib()
+    for i in range(0, n, 3):
+        seed = (int(gid[i]) * (42 + int(nm[i]))) & 0xFFFFFFFFFFFFFFFF
+        assert int(ou[i]) == OL.c4o_rng_first_u32(seed)
+        assert int(oc[i]) == O.sample_move(int(gid[i]), int(nm[i]), pol[i], float(temps[i])), i

@@ -1,0 +1,209 @@
+"""GPU parity of the tree path: the fused HIP step kernel vs the CPU oracle, bit for bit,
+through the C ABI.  Tiers follow SURVEY 8c: T2 = the reference's own MCTS known-answer tests
+run ON THE DEVICE (constant evaluator), T1 = whole self-play games under the integer-hash
+evaluator, compared per game_id sample by sample."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+F = np.float32
+UNIFORM = float(F(1.0) / F(7.0))
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from c4a0_amd.session import DeviceSession
+    from oracle import c4oracle as O
+
+    return DeviceSession, O, torch.device("cuda:0")
+
+
+def device_run_mcts(DeviceSession, pos, n_iter, c_expl=4.0, c_ply=0.01, blocks=None):
+    """mcts.rs:469-485 `run_mcts` on the GPU: one game, constant evaluator, no moves."""
+    from tests.helpers import uniform_eval_torch
+
+    s = DeviceSession(1, 1 << 30, c_expl, c_ply, blocks_per_slot=blocks or (n_iter + 8), no_moves=True)
+    s.set_games([(0, 0, 0)], [pos])
+    s.bind()
+    s.start()
+    s.evaluate(uniform_eval_torch)  # constant: evaluate once, the bound tensors never change
+    for _ in range(n_iter):
+        s.step()
+    pol, qp, qn, n, root = s.root_stats(0)
+    c = s.counters()
+    s.close()
+    assert c["error"] == 0 and n == n_iter and root == pos
+    return pol, qp, qn, c
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a, dtype=np.float32).view(np.uint32), np.asarray(b, dtype=np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("n_iter", [1, 2, 15, 47, 106, 1000])
+def test_empty_board_kats_match_oracle(env, n_iter):
+    # mcts.rs:488-514 (prefers_center 1000, depth_one 15, depth_two 106, depth_uneven 47)
+    DeviceSession, O, dev = env
+    pol, qp, qn, c = device_run_mcts(DeviceSession, (0, 0), n_iter)
+    opol, oqp, oqn, g = O.run_mcts(O.Pos(0, 0), n_iter, 4.0, 0.01)
+    assert _same(pol, opol) and _same([qp, qn], [oqp, oqn])
+    oc = g.counters()
+    assert (c["sims"], c["select_levels"], c["backup_nodes"], c["expansions"]) == \
+           (oc["sims"], oc["select_levels"], oc["backup_nodes"], oc["expansions"])
+    if n_iter in (15, 106):
+        assert np.all(np.abs(pol - F(UNIFORM)) < 1e-8)
+    if n_iter == 47:
+        assert np.array_equal(np.round(pol * 46).astype(int), [6, 6, 6, 7, 7, 7, 7])  # last-max tie-break
+    if n_iter == 1000:
+        assert pol[3] > F(UNIFORM)
+
+
+TACTICAL = [  # (rows, n_iter, check) -- mcts.rs:519-632
+    (["⚫⚫⚫⚫⚫⚫⚫"] * 4 + ["⚫🔵🔵🔵⚫⚫⚫", "⚫🔴🔴🔴⚫⚫⚫"], 10_000,
+     lambda p, qp, qn: p[0] + p[4] > 0.99 and qp > 0.92 and qn > 0.99),
+    (["⚫⚫⚫⚫⚫⚫⚫"] * 4 + ["⚫⚫🔵🔵⚫⚫⚫", "⚫⚫🔴🔴⚫⚫⚫"], 10_000,
+     lambda p, qp, qn: p[1] + p[4] > 0.98 and qp > 0.90 and qn > 0.98 and qn > qp),
+    (["⚫⚫⚫⚫⚫⚫⚫"] * 3 + ["⚫🔴🔵🔵⚫⚫⚫", "⚫🔵🔴🔴🔴⚫⚫", "⚫🔵🔵🔴🔵🔴⚫"], 10_000,
+     lambda p, qp, qn: p[5] > 0.99 and qp > 0.86 and qn > 0.99 and qn > qp),
+    (["⚫⚫⚫🔵⚫⚫⚫", "⚫🔵🔵🔵⚫⚫⚫", "⚫🔴🔵🔵⚫⚫⚫", "⚫🔴🔴🔴⚫⚫⚫", "⚫🔴🔴🔴⚫⚫⚫", "⚫🔵🔴🔵⚫⚫⚫"], 10_000,
+     lambda p, qp, qn: p[4] > 0.99 and qp > 0.82 and qn > 0.99 and qn > qp),
+    (["⚫⚫⚫⚫⚫⚫⚫"] * 4 + ["⚫🔴🔴⚫⚫⚫⚫", "⚫🔵🔵🔵⚫⚫⚫"], 30_000,   # losing_position, shortened from 300k
+     lambda p, qp, qn: qp < -0.9 and qn < -0.95 and qn < qp),
+]
+
+
+@pytest.mark.parametrize("case", range(len(TACTICAL)))
+def test_tactical_kats_match_oracle(env, case):
+    DeviceSession, O, dev = env
+    rows, n_iter, check = TACTICAL[case]
+    pos = O.from_rows(rows)
+    pol, qp, qn, c = device_run_mcts(DeviceSession, pos.key(), n_iter)
+    opol, oqp, oqn, g = O.run_mcts(pos, n_iter, 4.0, 0.01)
+    assert check(pol, qp, qn)
+    assert _same(pol, opol) and _same([qp, qn], [oqp, oqn])
+
+
+def _play(DeviceSession, reqs, n_slots, n_iter, c_expl, c_ply, evaluator, planes_dtype=torch.float32):
+    s = DeviceSession(n_slots, n_iter, c_expl, c_ply, planes_dtype=planes_dtype)
+    s.set_games(reqs)
+    steps = s.run(evaluator, max_steps=2_000_000)
+    recs = s.drain_samples()
+    c = s.counters()
+    counts = s.sample_counts()
+    s.close()
+    return recs, c, counts, steps
+
+
+@pytest.mark.parametrize("n_games,n_slots,n_iter,c_expl", [
+    (32, 32, 10, 6.6),     # BASELINE config 1 shape (32 games, n_mcts = 10)
+    (96, 24, 25, 6.6),     # more games than slots: finished games are replaced mid-run
+    (40, 64, 5, 1.4),      # fewer games than slots: idle slots
+    (16, 16, 100, 6.6),    # n_mcts = 100 (BASELINE metric setting), few games
+    (8, 8, 2, 4.0),        # smallest gate with a visited child: a move every other simulation
+])
+def test_self_play_hash_evaluator_bit_identical(env, n_games, n_slots, n_iter, c_expl):
+    """T1: every sample of every game identical to the oracle (per game_id, order-free)."""
+    DeviceSession, O, dev = env
+    from tests.helpers import hash_eval_torch, oracle_samples_by_game, samples_by_game
+
+    # ids include 0 (seed 0 on every move) and colliding seeds 43*42 == 42*43 (mcts.rs:215)
+    ids = [0, 42, 43, 1 << 40, (1 << 64) - 1][: min(5, n_games)] + list(range(1000, 1000 + n_games))
+    reqs = [(gid, 0, 0) for gid in ids[:n_games]]
+    recs, c, counts, steps = _play(DeviceSession, reqs, n_slots, n_iter, c_expl, 0.01, hash_eval_torch)
+    ores, ost = O.self_play(reqs, 1 << 20, n_iter, c_expl, 0.01, "hash")
+    got, want = samples_by_game(recs), oracle_samples_by_game(ores)
+    assert set(got) == set(want)
+    for gid in want:
+        assert got[gid] == want[gid], f"game {gid} differs"
+    assert c["games_done"] == n_games and c["samples"] == ost["n_samples"] == len(recs)
+    assert np.array_equal(counts, [len(ores[g]) for g, _, _ in reqs])
+    # device counters are the exact roofline numerators: they must equal the oracle's
+    assert c["sims"] + c["ref_skipped_sims"] == ost["sims"]
+    assert c["ref_skipped_sims"] == ost["sims_terminal_root"]
+    # the device does not run the select whose leaf a move discards in the same job
+    assert c["select_levels"] == ost["select_levels"] - ost["select_levels_discarded"]
+    assert c["backup_nodes"] == ost["backup_nodes"]
+    assert c["expansions"] == ost["expansions"]
+    assert c["moves"] == ost["moves"]
+
+
+def test_self_play_uniform_evaluator_structure_and_parity(env):
+    """T2 + self_play.rs:405-458 structural invariants, on the device, bf16 planes."""
+    DeviceSession, O, dev = env
+    from tests.helpers import oracle_samples_by_game, samples_by_game, uniform_eval_torch
+
+    reqs = [(i, 0, 0) for i in range(48)]
+    recs, c, counts, _ = _play(DeviceSession, reqs, 16, 50, 1.0, 0.01, uniform_eval_torch, planes_dtype=torch.bfloat16)
+    ores, _ = O.self_play(reqs, 10, 50, 1.0, 0.01, "uniform")
+    got, want = samples_by_game(recs), oracle_samples_by_game(ores)
+    assert got == want
+    for gid, ss in got.items():
+        assert len(ss) >= 7
+        assert sum(1 for s in ss if (s[0], s[1]) == (0, 0)) == 1
+        term = [s for s in ss if O.terminal_state(O.Pos(s[0], s[1])) != 0]
+        assert len(term) == 1 and term[0] is ss[-1]
+        assert np.frombuffer(term[0][4], dtype=np.float32)[0] in (-1.0, 0.0, 1.0)
+
+
+def test_errors_are_raised_not_hidden(env):
+    """Reference panics become status codes: NaN in UCT (utils.rs:12), all -inf policy
+    (mcts.rs:421-425), arena overflow (build-specific)."""
+    DeviceSession, O, dev = env
+    from c4a0_amd._lib import C4Error
+
+    def nan_eval(planes):
+        g = planes.shape[0]
+        return torch.full((g, 7), float("nan"), device=planes.device), torch.zeros((g, 2), device=planes.device)
+
+    def neginf_eval(planes):
+        g = planes.shape[0]
+        return torch.full((g, 7), float("-inf"), device=planes.device), torch.zeros((g, 2), device=planes.device)
+
+    def nan_q_eval(planes):
+        g = planes.shape[0]
+        return torch.zeros((g, 7), device=planes.device), torch.full((g, 2), float("nan"), device=planes.device)
+
+    from tests.helpers import uniform_eval_torch
+    for ev, code, kw in ((nan_eval, 4, {}), (neginf_eval, 4, {}), (nan_q_eval, 3, {}),
+                         (uniform_eval_torch, 5, {"blocks_per_slot": 4})):
+        s = DeviceSession(4, 10, 6.6, 0.01, **kw)
+        s.set_games([(i, 0, 0) for i in range(4)])
+        with pytest.raises(C4Error) as ei:
+            s.run(ev, max_steps=5000, poll_every=4)
+        assert ei.value.status == code
+        s.close()
+
+
+def test_gate_of_one_iteration_matches_reference_behaviour(env):
+    """n_mcts_iterations = 1: the root's children never have visits, root_policy falls back to
+    UNIFORM over all 7 columns (mcts.rs:404-406) and a full column can be sampled, where the
+    reference panics (mcts.rs:196-200).  Device and oracle must agree game by game: same
+    samples, or the same failure."""
+    DeviceSession, O, dev = env
+    from c4a0_amd._lib import C4Error, ERR_ILLEGAL_MOVE
+    from tests.helpers import hash_eval_torch, oracle_samples_by_game, samples_by_game
+
+    n_fail = 0
+    for gid in range(40):
+        reqs = [(gid, 0, 0)]
+        try:
+            ores, _ = O.self_play(reqs, 64, 1, 4.0, 0.01, "hash")
+            want = oracle_samples_by_game(ores)
+        except RuntimeError:
+            want = None
+        s = DeviceSession(1, 1, 4.0, 0.01)
+        s.set_games(reqs)
+        try:
+            s.run(hash_eval_torch, max_steps=500, poll_every=1)
+            got = samples_by_game(s.drain_samples())
+        except C4Error as e:
+            assert e.status == ERR_ILLEGAL_MOVE
+            got = None
+        s.close()
+        assert got == want, gid
+        n_fail += want is None
+    assert 0 <= n_fail < 40

@@ -1,0 +1,68 @@
+"""The NN restatement (c4a0_amd/nn.py) against golden vectors produced by the REFERENCE's own
+src/c4a0/nn.py (tests/golden/make_nn_fixture.py, run in the development container).
+Floating point: tolerance 1e-5 absolute in f32 (different op order after BN folding)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig, flops_per_leaf
+
+FIX = os.path.join(os.path.dirname(__file__), "golden", "nn_fixture.npz")
+TOL = 1e-5
+
+
+def _load():
+    z = np.load(FIX)
+    cfg = ModelConfig(*[int(v) for v in z["cfg"]])
+    model = ConnectFourNet(cfg)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return z, cfg, model.eval()
+
+
+def test_state_dict_keys_are_the_references():
+    z, cfg, model = _load()
+    assert set(model.state_dict().keys()) == {k[3:] for k in z.files if k.startswith("sd/")}
+    assert "conv.1.block.2.running_mean" in model.state_dict() and "fc_policy.0.0.weight" in model.state_dict()
+
+
+def test_module_forward_matches_reference_outputs():
+    z, cfg, model = _load()
+    with torch.no_grad():
+        lp, qp, qn = model(torch.from_numpy(z["x"]))
+    assert np.abs(lp.numpy() - z["policy_logprobs"]).max() <= TOL
+    assert np.abs(qp.numpy() - z["q_penalty"]).max() <= TOL
+    assert np.abs(qn.numpy() - z["q_no_penalty"]).max() <= TOL
+
+
+def test_bn_folded_f32_inference_matches_reference_outputs():
+    z, cfg, model = _load()
+    net = InferenceNet(model, torch.device("cpu"), dtype=torch.float32)
+    lp, q = net(torch.from_numpy(z["x"]))
+    assert lp.dtype == torch.float32 and q.shape == (z["x"].shape[0], 2)
+    assert np.abs(lp.numpy() - z["policy_logprobs"]).max() <= TOL
+    assert np.abs(q[:, 0].numpy() - z["q_penalty"]).max() <= TOL
+    assert np.abs(q[:, 1].numpy() - z["q_no_penalty"]).max() <= TOL
+    assert np.allclose(np.exp(lp.numpy()).sum(1), 1.0, atol=1e-5)   # nn_test.py:26-40: exp(logprobs) sums to 1
+    assert np.all(np.abs(q.numpy()) <= 1.0)
+    out_lp, out_q = torch.empty(24, 7), torch.empty(24, 2)
+    net(torch.from_numpy(z["x"]), out_logprobs=out_lp, out_q=out_q)
+    assert torch.equal(out_lp, lp) and torch.equal(out_q, q)
+
+
+def test_flops_per_leaf_matches_survey():
+    # 1x32 16.1 M; 4x32 20.7 M; 8x64 107.5 M
+    assert round(flops_per_leaf(ModelConfig(1, 32, 4, 2)) / 1e6, 1) == 16.1
+    assert round(flops_per_leaf(ModelConfig(4, 32, 4, 2)) / 1e6, 1) == 20.7
+    assert round(flops_per_leaf(ModelConfig(8, 64, 4, 2)) / 1e6, 1) == 107.5
+
+
+def test_param_counts_match_survey():
+    # SURVEY 8a a20 [probe]: 1x32 7 272 745; 4x32 7 328 425; 8x64 29 550 921
+    n = lambda cfg: sum(p.numel() for p in ConnectFourNet(cfg).parameters())
+    assert n(ModelConfig(1, 32, 4, 2)) == 7_272_745
+    assert n(ModelConfig(4, 32, 4, 2)) == 7_328_425
+    assert n(ModelConfig(8, 64, 4, 2)) == 29_550_921
