@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play games/sec of the MI355X-native generator (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one lock-step MCTS simulation for every resident game: the ResNet evaluates the
+G leaf positions (HIP-graph replay, bf16) and the fused HIP step kernel consumes the outputs
+(expand, backup, move/finish/refill, select, encode the next leaves).  Workload at every N:
+BASELINE config 2 per GPU -- 4 096 concurrent games, n_mcts_iterations = 100, 4-block/32-channel
+ResNet in bf16, c_exploration 6.6, c_ply_penalty 0.01, game ids sharded id % N (weak scaling;
+config 3 is exactly this at N = 8).  Synthetic data: empty-board starts, random-init network
+(torch.manual_seed(1337)).  Before the warm-up the session is rolled forward until finished
+games have been replaced at least once, so the timed steps see the steady-state mix of game
+phases; `value` counts games COMPLETED inside the timed steps.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (fused tree step kernel vs HBM),
+"cpu_baseline" (the CPU oracle in the reference's topology, timed on this box's host cores),
+"nn" (evaluator FLOP rate).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def algorithmic_bytes(c: dict, planes_bytes_per_elem: int) -> dict:
+    """SURVEY 8(d) canonical-node traffic model, from the DEVICE-counted S, K, E:
+    select/backup 92*S + 28*K, expand 332*E, leaf encode 84 elements per sim."""
+    sb = 92 * c["select_levels"] + 28 * c["backup_nodes"]
+    ex = 332 * c["expansions"]
+    enc = 84 * planes_bytes_per_elem * c["sims"]
+    return {"select_backup": sb, "expand": ex, "encode": enc, "total": sb + ex + enc}
+
+
+def usable_cores() -> int:
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:  # cgroup v2 CPU quota, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(net, device, n_iter: int, threads: int, budget_s: float = 20.0):
+    """The reference's CPU path restated: tree search on host cores (oracle, OpenMP over games =
+    the MctsThreads of self_play.rs:78-106), leaves batched to the SAME network on the GPU through
+    the numpy callback round trip of nn.py:119-130.  Bounded sample of the same workload: a small
+    probe sizes the sample to about `budget_s` seconds."""
+    from oracle import c4oracle as O
+
+    def cb(_model_id, x):
+        with torch.no_grad():
+            lp, q = net(torch.from_numpy(x).to(device))
+            lp, q = lp.float().cpu().numpy(), q.float().cpu().numpy()
+        return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
+
+    def run(n_games):
+        reqs = [(i, 0, 0) for i in range(n_games)]
+        t0 = time.perf_counter()
+        _res, st = O.self_play(reqs, 4096, n_iter, 6.6, 0.01, cb, n_threads=threads)
+        return time.perf_counter() - t0, st
+
+    dt, st = run(32)  # probe
+    n_games = int(min(4096, max(32, 32 * budget_s / max(dt, 1e-3) * 0.5)))
+    n_games = 1 << (n_games.bit_length() - 1)
+    if n_games > 32:
+        dt, st = run(n_games)
+    else:
+        n_games = 32
+    return {"value": n_games / dt, "unit": "games/s", "cores": threads, "kind": "port",
+            "sample": f"{n_games} games, n_mcts_iterations={n_iter}, C oracle (OpenMP x{threads}) + the same bf16 ResNet on the GPU via the numpy callback round trip; {dt:.1f} s",
+            "sims_per_s": st["sims"] / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--games-per-gpu", type=int, default=4096, help="resident games per GPU (BASELINE config 2: 4096)")
+    ap.add_argument("--n-mcts", type=int, default=100)
+    ap.add_argument("--blocks", type=int, default=4, help="residual blocks")
+    ap.add_argument("--channels", type=int, default=32)
+    ap.add_argument("--preroll", type=int, default=-1, help="untimed steps to reach steady state (-1 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--eager", action="store_true", help="do not capture the evaluator in a HIP graph")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from c4a0_amd.nn import ConnectFourNet, GraphedEvaluator, InferenceNet, ModelConfig, flops_per_leaf
+    from c4a0_amd.session import DeviceSession
+
+    G, n_iter = args.games_per_gpu, args.n_mcts
+    cfg = ModelConfig(args.blocks, args.channels, 4, 2)
+    torch.manual_seed(1337)
+    net = InferenceNet(ConnectFourNet(cfg), device, dtype=torch.bfloat16)
+
+    sess = DeviceSession(G, n_iter, 6.6, 0.01, device=device, planes_dtype=torch.bfloat16)
+    preroll = args.preroll if args.preroll >= 0 else int(2.0 * 15.0 * n_iter)  # ~2 game lengths of sims
+    total_steps = preroll + args.warmup + args.steps
+    sims_per_game_lo = 8 * n_iter  # generous lower bound on sims per game -> upper bound on games needed
+    n_games = int(G * (2 + total_steps / sims_per_game_lo)) + G
+    # ids sharded id % world == rank: rank r plays ids r, r+W, ...
+    sess.set_games([(rank + world * i, 0, 0) for i in range(n_games)])
+    sess.bind()
+    sess.start()
+    evaluator = net if args.eager else GraphedEvaluator(net, sess.planes, sess.logprobs, sess.q)
+
+    def run_steps(k, events=None):
+        for i in range(k):
+            sess.evaluate(evaluator)
+            if events is not None:
+                events[i][0].record()
+                sess.step()
+                events[i][1].record()
+            else:
+                sess.step()
+
+    run_steps(preroll)
+    run_steps(args.warmup)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    c0 = sess.counters()  # synchronises the stream
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps, ev)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    c1 = sess.counters()
+    if c1["error"]:
+        sys.exit(f"device error {c1['error']} in slot {c1['error_slot']}")
+    if c1["games_started"] >= n_games:
+        sys.exit("bench ran out of queued games; raise n_games")
+    d = {k: c1[k] - c0[k] for k in c1 if k not in ("error", "error_slot")}
+    elapsed = t1 - t0
+    step_kernel_ms = sum(a.elapsed_time(b) for a, b in ev)
+
+    games, sims, elapsed_max = float(d["games_done"]), float(d["sims"]), elapsed
+    if dist is not None:
+        t = torch.tensor([games, sims, float(d["ref_skipped_sims"])], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        m = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        games, sims, skipped = t.tolist()
+        elapsed_max = float(m.item())
+    else:
+        skipped = float(d["ref_skipped_sims"])
+
+    if rank == 0:
+        ab = algorithmic_bytes(d, 2)
+        avg_kernel_s = step_kernel_ms / 1e3 / max(1, args.steps)
+        achieved = ab["total"] / max(1, args.steps) / avg_kernel_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "step_kernel_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        fl = flops_per_leaf(cfg)
+        nn_s = max(1e-9, elapsed - step_kernel_ms / 1e3)
+        out = {
+            "metric": "self-play games/sec (and MCTS sims/sec) at n_mcts=100",
+            "value": games / elapsed_max,
+            "unit": "games/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config 2 per GPU: {G} concurrent games, n_mcts_iterations={n_iter}, "
+                                   f"{cfg.n_residual_blocks}-block/{cfg.conv_filter_size}-ch ResNet bf16, c_exploration=6.6, c_ply_penalty=0.01",
+                       "games_per_gpu": G, "n_mcts_iterations": n_iter, "parallelism": f"games sharded id%{world}",
+                       "evaluator": "eager" if args.eager else "hip-graph", "preroll_steps": preroll,
+                       "tree_dtype": "u64 bitboards + f32 UCT"},
+            "sims_per_s": sims / elapsed_max,
+            "ref_equivalent_sims_per_s": (sims + skipped) / elapsed_max,
+            "games_completed": games,
+            "sims_per_game": sims / max(1.0, games),
+            "roofline": {"bound": "hbm", "kernel": "c4_step_kernel (expand+backup+move+select+encode, fused)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic,
+                         "avg_launch_us": avg_kernel_s * 1e6,
+                         "algorithmic_bytes_per_launch": ab["total"] / max(1, args.steps),
+                         "bytes_per_sim": {k: v / max(1, d["sims"]) for k, v in ab.items()},
+                         "S_per_sim": d["select_levels"] / max(1, d["sims"]), "K_per_sim": d["backup_nodes"] / max(1, d["sims"]),
+                         "E_per_sim": d["expansions"] / max(1, d["sims"])},
+            "nn": {"bound": "mfma", "flops_per_leaf": fl, "achieved": fl * G * args.steps / nn_s / 1e12,
+                   "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": fl * G * args.steps / nn_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                   "note": "wall time minus step-kernel time; includes launch gaps"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(net, device, n_iter, min(usable_cores(), 64), args.cpu_baseline_seconds)
+            except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out))
+    sess.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,7 @@ SIGNATURES = {
     "c4_session_poll": (C.c_int, [_vp, _P(C.c_uint64), _P(C.c_uint32)]),
     "c4_session_sample_counts": (C.c_int, [_vp, _P(C.c_uint32), C.c_uint64]),
     "c4_session_drain_samples": (C.c_int, [_vp, _P(SampleRec), C.c_uint64, _P(C.c_uint64)]),
+    "c4_session_pack_samples": (C.c_int, [_vp, _vp, C.c_uint64, _P(C.c_uint64)]),
     "c4_session_sample_store": (C.c_int, [_vp, _P(_vp), _P(_vp), _P(C.c_uint64)]),
     "c4_session_root_stats": (C.c_int, [_vp, C.c_uint32, _P(C.c_float), _P(C.c_float), _P(C.c_float),
                                         _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint64)]),
@@ -88,6 +89,13 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: the HIP extension is the product and there is no fallback. "
                 "Build it with `python c4a0_amd/csrc/build.py` (hipcc --offload-arch=gfx950).")
+        # PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7, but its libraries ask
+        # for "libamdhip64.so").  If our library -- linked against "libamdhip64.so.7" -- pulled in
+        # /opt/rocm's copy first, torch would load a SECOND HIP runtime into the process and one
+        # of the two would see no device.  Loading torch first makes the loader resolve our
+        # dependency to the runtime torch already mapped, so kernels, streams and tensors share it.
+        import torch  # noqa: F401
+
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

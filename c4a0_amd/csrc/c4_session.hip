@@ -507,6 +507,17 @@ __global__ void k_sample_move(const uint64_t* game_id, const uint32_t* n_moves, 
   if (out_u32) out_u32[i] = u;
 }
 
+// K6: pack finished games' records contiguously (one wavefront per game, 4 records per pass)
+__global__ __launch_bounds__(64) void k_pack_samples(const c4_sample_rec* src, const uint32_t* counts,
+                                                     const unsigned long long* offsets, uint64_t n_games, c4_sample_rec* dst) {
+  const uint64_t game = blockIdx.x;
+  if (game >= n_games) return;
+  const uint32_t n = counts[game];
+  const uint4* s4 = (const uint4*)(src + game * C4_MAX_SAMPLES_PER_GAME);
+  uint4* d4 = (uint4*)(dst + offsets[game]);
+  for (uint32_t i = threadIdx.x; i < n * 4u; i += 64) d4[i] = s4[i];  // 64-byte record = 4 x 16 bytes
+}
+
 // ------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------
@@ -755,6 +766,32 @@ int c4_session_drain_samples(c4_session* s, c4_sample_rec* dst_host, uint64_t ca
     }
     i = j;
   }
+  return C4_OK;
+}
+
+int c4_session_pack_samples(c4_session* s, c4_sample_rec* dst_dev, uint64_t cap, uint64_t* n_written) {
+  if (!s || !n_written) return fail(C4_ERR_BAD_ARG, "null argument");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  std::vector<uint32_t> counts(s->n_games ? s->n_games : 1);
+  if (s->n_games) HIP_TRY(hipMemcpy(counts.data(), s->p.sample_counts, s->n_games * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> offs(s->n_games ? s->n_games : 1);
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < s->n_games; i++) { offs[i] = total; total += counts[i]; }
+  *n_written = total;
+  if (!dst_dev || total == 0) return C4_OK;  // size query
+  if (cap < total) return fail(C4_ERR_BAD_ARG, "destination too small");
+  unsigned long long* offs_dev = nullptr;
+  HIP_TRY(hipMalloc(&offs_dev, s->n_games * sizeof(unsigned long long)));
+  hipError_t e = hipMemcpy(offs_dev, offs.data(), s->n_games * sizeof(unsigned long long), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)s->n_games), dim3(64), 0, s->stream, s->p.samples, s->p.sample_counts,
+                       offs_dev, s->n_games, dst_dev);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  }
+  (void)hipFree(offs_dev);
+  if (e != hipSuccess) return fail(C4_ERR_HIP, std::string("pack_samples: ") + hipGetErrorString(e));
   return C4_OK;
 }
 

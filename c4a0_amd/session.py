@@ -117,6 +117,15 @@ class DeviceSession:
         check(self.L.c4_session_drain_samples(self._h, buf.ctypes.data_as(C.POINTER(SampleRec)), n.value, C.byref(n)))
         return buf[: n.value]
 
+    def pack_samples_device(self) -> torch.Tensor:
+        """Finished games' records packed into one device tensor uint8[n, 64] (kernel K6)."""
+        n = C.c_uint64()
+        check(self.L.c4_session_pack_samples(self._h, None, 0, C.byref(n)))
+        out = torch.empty((max(1, n.value), 64), dtype=torch.uint8, device=self.device)
+        if n.value:
+            check(self.L.c4_session_pack_samples(self._h, C.c_void_p(out.data_ptr()), n.value, C.byref(n)))
+        return out[: n.value]
+
     def root_stats(self, slot: int = 0):
         pol = (C.c_float * 7)()
         qp, qn = C.c_float(), C.c_float()

@@ -137,6 +137,11 @@ int c4_session_poll(c4_session* s, uint64_t* games_done, uint32_t* error);
  * packed in reqs order into dst_host (capacity cap records).  Both synchronise the stream. */
 int c4_session_sample_counts(c4_session* s, uint32_t* counts_host, uint64_t n_games);
 int c4_session_drain_samples(c4_session* s, c4_sample_rec* dst_host, uint64_t cap, uint64_t* n_written);
+/* K6: packs the records of finished games, in reqs order, into the
+ * caller's DEVICE buffer dst_dev (capacity cap records) so that one rank's samples are one
+ * contiguous tensor for the RCCL all-gather.  *n_written = records packed.  Synchronises (the
+ * per-game counts are prefix-summed on the host). */
+int c4_session_pack_samples(c4_session* s, c4_sample_rec* dst_dev, uint64_t cap, uint64_t* n_written);
 /* Device views for collectives (RCCL all-gather of samples): records [n_games][43], counts [n_games]. */
 int c4_session_sample_store(c4_session* s, const c4_sample_rec** recs_dev, const uint32_t** counts_dev, uint64_t* n_games);
 

@@ -936,7 +936,7 @@ int c4o_self_play(const c4o_game_metadata* reqs, uint64_t n_games, int max_nn_ba
 
     /* MctsThread::loop_once for every answered game (self_play.rs:225-236, 268-323) */
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads) if (n_threads > 1)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(n_threads) if (n_threads > 1 && n_pending >= 512)
 #endif
     for (uint64_t k = 0; k < n_pending; k++) {
       uint64_t gi = pending[k];

@@ -14,6 +14,11 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+# OpenMP workers must sleep, not spin, between the per-tick parallel regions: the evaluator
+# callback runs on the main thread in between and would otherwise compete with spinning workers.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_DIR, "libc4oracle.so")
 

@@ -1,0 +1,143 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol the
+header declares (no compute without a GPU), the product never imports the oracle, and the
+result classes mirror the reference's PyO3 classes (types.rs, pybridge.rs)."""
+import ctypes as C
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from c4a0_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "c4a0_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(c4_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_struct_layouts_match_header():
+    from c4a0_amd import _lib
+    from c4a0_amd.session import SAMPLE_DTYPE
+
+    assert C.sizeof(_lib.SampleRec) == 64 == SAMPLE_DTYPE.itemsize
+    assert C.sizeof(_lib.GameMetadataC) == 24
+    assert C.sizeof(_lib.Config) == 32
+    assert C.sizeof(_lib.Counters) == 9 * 8 + 8
+    assert [n for n, *_ in _lib.SampleRec._fields_] == list(SAMPLE_DTYPE.names)
+
+
+def test_no_gpu_is_reported_not_faked():
+    """Without a device the product refuses to run; it never falls back to a CPU path."""
+    import torch
+    from c4a0_amd import _lib
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    cfg = _lib.Config(4, 0, 10, 6.6, 0.01, 0, 0, 0)
+    h = C.c_void_p()
+    assert _lib.lib().c4_session_create(C.byref(cfg), C.byref(h)) == _lib.ERR_NO_DEVICE
+    from c4a0_amd import GameMetadata, play_games
+    with pytest.raises(RuntimeError):
+        play_games([GameMetadata(0, 0, 0)], 8, 2, 1.4, 0.01, lambda m, x: None)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _dirs, files in os.walk(os.path.join(ROOT, "c4a0_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "c4oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+# ---- result classes -------------------------------------------------------------------------
+def _mk():
+    from c4a0_amd import GameMetadata, GameResult, PlayGamesResult, Sample
+
+    f = np.float32
+    s0 = Sample(0, 0, [f(1) / f(7)] * 7, f(-0.93), f(-1.0))
+    s1 = Sample(0b1000, 0, [0.5, 0.25, 0.125, 0.0625, 0.03125, 0.015625, 0.015625], f(0.93), f(1.0))
+    term = Sample(0b1111 | (0b111 << 7), 0, [f(1) / f(7)] * 7, f(-0.93), f(-1.0))  # opponent has 4 on the bottom row
+    g0 = GameResult(GameMetadata(7, 1, 2), [s0, s1, term])
+    g1 = GameResult(GameMetadata((1 << 64) - 1, 0, 0), [s0, term])
+    return PlayGamesResult([g0, g1]), (s0, s1, term)
+
+
+def test_sample_to_numpy_and_flip_h():
+    pgr, (s0, s1, term) = _mk()
+    pos, pol, qp, qn = s1.to_numpy()                        # types.rs:125-147, training.py:329-332
+    assert pos.shape == (2, 6, 7) and pos.dtype == np.float32 and pol.shape == (7,) and qp.shape == () and qn.shape == ()
+    assert pos[1, 0, 3] == 1.0 and pos.sum() == 1.0         # one opponent piece at row 0 col 3
+    fl = s1.flip_h()                                        # types.rs:115-122
+    assert fl.mask == 0b1000 and np.array_equal(fl.policy, s1.policy[::-1])
+    s = type(s1)(0b1, 0b1, s1.policy, 0.0, 0.0).flip_h()
+    assert s.mask == 1 << 6 and s.value == 1 << 6
+    assert s1.flip_h().flip_h() == s1
+    assert s1.pos_str().splitlines()[-1] == "⚫⚫⚫🔵⚫⚫⚫"
+
+
+def test_player0_score():                                   # types.rs:77-99
+    pgr, _ = _mk()
+    # terminal sample: 7 pieces (odd ply), OpponentWin for the side to move => player 1 to move lost => player 0 won
+    assert pgr.results[0].player0_score() == 1.0
+    from c4a0_amd import GameMetadata, GameResult
+    with pytest.raises(RuntimeError):
+        GameResult(GameMetadata(0, 0, 0), []).player0_score()
+
+
+def test_cbor_wire_format_is_serde_cbor_shaped():
+    """pybridge.rs:73-92: serde_cbor 0.11.2 output for the derive(Serialize) structs: maps keyed
+    by field names in declaration order, shortest ints, f32 as half when lossless."""
+    pgr, _ = _mk()
+    b = pgr.to_cbor()
+    assert b[:10] == bytes([0xA1, 0x67]) + b"results" + bytes([0x82])        # {"results": [2 items
+    assert b[10:20] == bytes([0xA2, 0x68]) + b"metadata"                     # {"metadata": ...
+    assert bytes([0x67]) + b"game_id" + bytes([0x07]) in b                   # game_id: 7 (1 byte)
+    assert bytes([0x1B]) + b"\xff" * 8 in b                                  # u64::MAX as 8-byte uint
+    assert bytes([0x66]) + b"policy" + bytes([0x87, 0xF9, 0x38, 0x00, 0xF9, 0x34, 0x00]) in b  # [0.5, 0.25 as f16
+    assert bytes([0xFA]) + np.array([np.float32(1) / np.float32(7)], dtype=">f4").tobytes() in b  # 1/7 needs f32
+    back = type(pgr).from_cbor(b)
+    assert back == pgr and back.to_cbor() == b
+    with pytest.raises(ValueError):
+        type(pgr).from_cbor(b[:-3])
+    with pytest.raises(ValueError):
+        type(pgr).from_cbor(b"\x00")
+
+
+def test_pickle_add_unique_split():
+    pgr, _ = _mk()
+    assert pickle.loads(pickle.dumps(pgr)) == pgr           # pybridge.rs:83-92 __getstate__/__setstate__
+    both = pgr + pgr                                        # pybridge.rs:95-106
+    assert len(both.results) == 4 and len(pgr.results) == 2
+    assert pgr.unique_positions() == 3                      # pybridge.rs:150-157
+    ids = [r.metadata.game_id for r in both.results]
+    tr1, te1 = both.split_train_test(0.5, 1337)             # pybridge_test.py:22-39
+    assert [r.metadata.game_id for r in both.results] == ids
+    tr2, te2 = both.split_train_test(0.5, 1337)
+    assert [s.pos_str() for s in tr1] == [s.pos_str() for s in tr2] and [s.pos_str() for s in te1] == [s.pos_str() for s in te2]
+    assert len(tr1) + len(te1) == sum(len(r.samples) for r in both.results)
+    assert both.split_train_test(1.0, 1)[1] == [] and both.split_train_test(0.0, 1)[0] == []
+    with pytest.raises(NotImplementedError):
+        pgr.score_policies("a", "b", "c")
+
+
+def test_results_from_records_roundtrip():
+    from c4a0_amd import GameMetadata
+    from c4a0_amd.results import results_from_records
+    from c4a0_amd.session import SAMPLE_DTYPE
+
+    recs = np.zeros(5, dtype=SAMPLE_DTYPE)
+    recs["game_id"] = [3, 3, 3, 9, 9]
+    recs["mask"] = [0, 1, 3, 0, 8]
+    recs["policy"][:, 2] = 1.0
+    recs["q_penalty"] = [0.5, -0.5, 0.5, 1, -1]
+    out = results_from_records([GameMetadata(3, 0, 0), GameMetadata(9, 0, 0)], recs, np.array([3, 2], dtype=np.uint32))
+    assert [len(r.samples) for r in out.results] == [3, 2]
+    assert out.results[1].samples[1].mask == 8 and out.results[0].samples[1].q_penalty == np.float32(-0.5)

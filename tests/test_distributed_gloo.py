@@ -1,0 +1,86 @@
+"""The N>1 path on CPU: world_size-2 gloo run of the sharding + variable-length sample
+all-gather used on 8 GPUs (c4a0_amd/distributed.py).  Each rank produces the records of its
+shard (here with the oracle, standing in for the GPU session), all-gathers them and rebuilds the
+request-order result; it must equal the single-process result game by game."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _records_for(ids):
+    from c4a0_amd.session import SAMPLE_DTYPE
+    from oracle import c4oracle as O
+
+    res, _ = O.self_play([(g, 0, 0) for g in ids], 64, 6, 6.6, 0.01, "hash")
+    recs, counts = [], []
+    for g in ids:
+        counts.append(len(res[g]))
+        for i, s in enumerate(res[g]):
+            r = np.zeros((), dtype=SAMPLE_DTYPE)
+            r["game_id"], r["mask"], r["value"] = g, s.mask, s.value
+            r["policy"], r["q_penalty"], r["q_no_penalty"] = s.policy, s.q_penalty, s.q_no_penalty
+            r["meta"] = i | ((1 << 16) if i == len(res[g]) - 1 else 0)
+            recs.append(r)
+    return np.array(recs, dtype=SAMPLE_DTYPE), np.array(counts, dtype=np.uint32)
+
+
+def _worker(rank, world, port, n_games, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from c4a0_amd.distributed import all_gather_records, merge_rank_records, shard_indices
+
+    ids = np.arange(100, 100 + n_games)
+    mine = ids[shard_indices(n_games, rank, world)]
+    recs, counts = _records_for(mine.tolist())
+    local = torch.from_numpy(recs.view(np.uint8).reshape(-1, 64).copy())
+    gathered = all_gather_records(local)
+    cnt_t = torch.zeros(n_games, dtype=torch.int64)  # counts travel the same way (padded to the largest shard)
+    cnt_t[: counts.size] = torch.from_numpy(counts.astype(np.int64))
+    all_counts = [torch.zeros_like(cnt_t) for _ in range(world)]
+    dist.all_gather(all_counts, cnt_t)
+    from c4a0_amd.session import SAMPLE_DTYPE
+    per_rank = [g.numpy().reshape(-1).view(SAMPLE_DTYPE) for g in gathered]
+    merged, mcounts = merge_rank_records(per_rank, n_games, world, [c.numpy().astype(np.uint32) for c in all_counts])
+    np.save(os.path.join(out_dir, f"merged_{rank}.npy"), merged)
+    np.save(os.path.join(out_dir, f"counts_{rank}.npy"), mcounts)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_games", [7, 10])
+def test_two_rank_shard_and_allgather(tmp_path, n_games):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, n_games, str(tmp_path)), nprocs=world, join=True)
+    want_recs, want_counts = _records_for(list(range(100, 100 + n_games)))
+    for rank in range(world):
+        got = np.load(tmp_path / f"merged_{rank}.npy")
+        cnt = np.load(tmp_path / f"counts_{rank}.npy")
+        assert np.array_equal(cnt, want_counts)
+        assert got.tobytes() == want_recs.tobytes()
+
+
+def test_shard_indices_partition():
+    from c4a0_amd.distributed import shard_indices
+
+    for n in (0, 1, 7, 64):
+        for w in (1, 2, 8):
+            parts = [shard_indices(n, r, w) for r in range(w)]
+            assert sorted(np.concatenate(parts).tolist()) == list(range(n))
