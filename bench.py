@@ -78,13 +78,11 @@ def cpu_baseline(net, device, n_iter: int, threads: int, budget_s: float = 20.0)
         _res, st = O.self_play(reqs, 4096, n_iter, 6.6, 0.01, cb, n_threads=threads)
         return time.perf_counter() - t0, st
 
-    dt, st = run(32)  # probe
-    n_games = int(min(4096, max(32, 32 * budget_s / max(dt, 1e-3) * 0.5)))
-    n_games = 1 << (n_games.bit_length() - 1)
-    if n_games > 32:
+    dt, st = run(128)  # probe: sizes the sample
+    n_games = int(min(8192, 128 * budget_s / max(dt, 1e-3)))
+    n_games = max(128, 1 << (n_games.bit_length() - 1))
+    if n_games > 128:
         dt, st = run(n_games)
-    else:
-        n_games = 32
     return {"value": n_games / dt, "unit": "games/s", "cores": threads, "kind": "port",
             "sample": f"{n_games} games, n_mcts_iterations={n_iter}, C oracle (OpenMP x{threads}) + the same bf16 ResNet on the GPU via the numpy callback round trip; {dt:.1f} s",
             "sims_per_s": st["sims"] / dt}

@@ -84,13 +84,53 @@ def _fold_bn(weight: torch.Tensor, bias: torch.Tensor, bn: nn.modules.batchnorm.
     return w.float(), b.float()
 
 
-class InferenceNet:
-    """Device-resident evaluator: planes[G,2,6,7] -> (policy_logprobs[G,7] f32, q[G,2] f32)."""
+def pack_tower_weights(conv_w, conv_b, channels: int):
+    """Re-order the (BN-folded) conv weights into the MFMA A-fragment order the HIP tower kernel
+    reads (c4a0_amd/csrc/c4_conv_tower.hip): for v_mfma_f32_16x16x32_bf16 lane l holds
+    A[row = l & 15][k = 8 (l >> 4) + j], j = 0..7.
 
-    def __init__(self, model: ConnectFourNet, device: torch.device, dtype: torch.dtype = torch.bfloat16):
+      conv_w[0]  [C, 2, 3, 3]  -> w0 [3 steps][C/16][64 lanes][8]: k-step s, k-group g <-> tap 4 s + g,
+                                  element j <-> input channel j (only j < 2 non-zero)
+      conv_w[1:] [C, C, 3, 3]  -> w  [layer][9 taps][C/16][C/32][64 lanes][8]:
+                                  W[co = 16 m + (l & 15)][ci = 32 kc + 8 (l >> 4) + j][tap]
+      conv_b     [C] each      -> bias [1 + 2 n_blocks][C] float32
+    """
+    c = channels
+    mt, kc = c // 16, c // 32
+    w0 = conv_w[0].float().reshape(c, 2, 9)                       # [co, ci, tap]
+    p0 = torch.zeros(3, mt, 4, 16, 8)                             # [s, m, g, co_l, j]
+    for s in range(3):
+        for g in range(4):
+            tap = 4 * s + g
+            if tap < 9:
+                p0[s, :, g, :, 0:2] = w0[:, :, tap].reshape(mt, 16, 2)
+    p0 = p0.reshape(3, mt, 64, 8)
+    layers = []
+    for w in conv_w[1:]:
+        wt = w.float().reshape(c, c, 9).permute(2, 0, 1)          # [tap, co, ci]
+        wt = wt.reshape(9, mt, 16, kc, 4, 8).permute(0, 1, 3, 4, 2, 5)  # [tap, m, kc, g, co_l, j]
+        layers.append(wt.reshape(9, mt, kc, 64, 8))
+    pw = torch.stack(layers) if layers else torch.zeros(0, 9, mt, kc, 64, 8)
+    bias = torch.stack([b.float() for b in conv_b])
+    return p0.contiguous(), pw.contiguous(), bias.contiguous()
+
+
+class InferenceNet:
+    """Device-resident evaluator: planes[G,2,6,7] -> (policy_logprobs[G,7] f32, q[G,2] f32).
+
+    `hip_tower=True` (default on a HIP device in bf16 with 32 or 64 channels) runs the conv tower
+    as the hand-written MFMA kernel `c4_conv_tower_bf16`; otherwise PyTorch-ROCm convs."""
+
+    def __init__(self, model: ConnectFourNet, device: torch.device, dtype: torch.dtype = torch.bfloat16,
+                 hip_tower: Optional[bool] = None):
         self.device = torch.device(device)
         self.dtype = dtype
         model = model.eval()
+        self.channels = model.config.conv_filter_size
+        can_tower = self.device.type == "cuda" and dtype == torch.bfloat16 and self.channels in (32, 64)
+        if hip_tower and not can_tower:
+            raise ValueError("hip_tower needs a HIP device, bf16 and 32 or 64 channels")
+        self.hip_tower = can_tower if hip_tower is None else bool(hip_tower)
         conv0 = model.conv[0]
         self.conv_w = [conv0.weight.detach().float()]
         self.conv_b = [conv0.bias.detach().float()]
@@ -116,28 +156,78 @@ class InferenceNet:
 
         self.pol_w, self.pol_b = head(model.fc_policy)
         self.val_w, self.val_b = head(model.fc_value)
+        if self.hip_tower:
+            from . import _lib
+
+            self._L = _lib.lib()
+            w0, w, bias = pack_tower_weights(self.conv_w, self.conv_b, self.channels)
+            self.tw0 = w0.to(self.device, torch.bfloat16).contiguous()
+            self.tw = w.to(self.device, torch.bfloat16).contiguous()
+            self.tbias = bias.to(self.device, torch.float32).contiguous()
+            # the tower emits [cell][channel]; the reference flattens "c h w" (nn.py:111): permute
+            # the input dimension of each head's first Linear once instead of the activations
+            c = self.channels
+            perm = lambda wt: wt.reshape(wt.shape[0], c, 42).permute(0, 2, 1).reshape(wt.shape[0], 42 * c)
+            self.pol_w[0] = perm(self.pol_w[0])
+            self.val_w[0] = perm(self.val_w[0])
+        self.pol_b32 = self.pol_b[-1].to(self.device, torch.float32).contiguous()
+        self.val_b32 = self.val_b[-1].to(self.device, torch.float32).contiguous()
+        self.fused_epilogue = self.device.type == "cuda" and hasattr(torch, "_addmm_activation")
         mv = lambda ts: [t.to(self.device, dtype).contiguous() for t in ts]
         self.conv_w = [w.to(self.device, dtype).contiguous(memory_format=torch.channels_last) for w in self.conv_w]
         self.conv_b = mv(self.conv_b)
         self.pol_w, self.pol_b, self.val_w, self.val_b = mv(self.pol_w), mv(self.pol_b), mv(self.val_w), mv(self.val_b)
 
     @torch.no_grad()
-    def forward(self, planes: torch.Tensor, out_logprobs: Optional[torch.Tensor] = None,
-                out_q: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def tower(self, planes: torch.Tensor) -> torch.Tensor:
+        """Conv tower -> flattened features [G, 42*C] (cell-major when hip_tower, else "c h w")."""
+        if self.hip_tower:
+            from ._lib import check
+            import ctypes as C
+
+            x = planes if planes.dtype == torch.bfloat16 else planes.to(torch.bfloat16)
+            x = x.contiguous()
+            g = x.shape[0]
+            out = torch.empty((g, 42 * self.channels), dtype=torch.bfloat16, device=self.device)
+            check(self._L.c4_conv_tower_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(self.tw0.data_ptr()),
+                                             C.c_void_p(self.tw.data_ptr()), C.c_void_p(self.tbias.data_ptr()),
+                                             g, self.channels, self.n_blocks, C.c_void_p(out.data_ptr()),
+                                             C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            return out
         x = planes.to(self.dtype)
         x = F.conv2d(x, self.conv_w[0], self.conv_b[0], padding=1)
         for i in range(self.n_blocks):
             y = F.conv2d(x, self.conv_w[1 + 2 * i], self.conv_b[1 + 2 * i], padding=1)
             y = F.conv2d(y, self.conv_w[2 + 2 * i], self.conv_b[2 + 2 * i], padding=1)
             x = x + F.relu(y)
-        x = x.reshape(x.shape[0], -1)
+        return x.reshape(x.shape[0], -1)
+
+    @torch.no_grad()
+    def forward(self, planes: torch.Tensor, out_logprobs: Optional[torch.Tensor] = None,
+                out_q: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        x = self.tower(planes)
         p = x
         for w, b in zip(self.pol_w[:-1], self.pol_b[:-1]):
-            p = F.relu(F.linear(p, w, b))
-        p = F.linear(p, self.pol_w[-1], self.pol_b[-1]).float()
+            p = self._linear_relu(p, w, b)
         v = x
         for w, b in zip(self.val_w[:-1], self.val_b[:-1]):
-            v = F.relu(F.linear(v, w, b))
+            v = self._linear_relu(v, w, b)
+        if self.hip_tower:
+            # both output layers + log-softmax + tanh in one HIP launch, written in place
+            from ._lib import check
+            import ctypes as C
+
+            g = x.shape[0]
+            lp = out_logprobs if out_logprobs is not None else torch.empty((g, 7), dtype=torch.float32, device=self.device)
+            q = out_q if out_q is not None else torch.empty((g, 2), dtype=torch.float32, device=self.device)
+            p, v = p.contiguous(), v.contiguous()
+            check(self._L.c4_head_out_bf16(C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()),
+                                           C.c_void_p(self.pol_w[-1].data_ptr()), C.c_void_p(self.val_w[-1].data_ptr()),
+                                           C.c_void_p(self.pol_b32.data_ptr()), C.c_void_p(self.val_b32.data_ptr()),
+                                           g, p.shape[1], C.c_void_p(lp.data_ptr()), C.c_void_p(q.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            return lp, q
+        p = F.linear(p, self.pol_w[-1], self.pol_b[-1]).float()
         v = F.linear(v, self.val_w[-1], self.val_b[-1]).float()
         if out_logprobs is None:
             lp = torch.log_softmax(p, dim=1)
@@ -145,6 +235,12 @@ class InferenceNet:
             lp = torch.log_softmax(p, dim=1, out=out_logprobs)
         q = torch.tanh(v) if out_q is None else torch.tanh(v, out=out_q)
         return lp, q
+
+    def _linear_relu(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """ReLU(x W^T + b) with the bias and ReLU in the GEMM epilogue (hipBLASLt) where available."""
+        if self.fused_epilogue:
+            return torch._addmm_activation(b, x, w.t(), use_gelu=False)
+        return F.relu(F.linear(x, w, b))
 
     __call__ = forward
 

@@ -177,6 +177,24 @@ int c4_apply_temperature(const float* policy_dev, const float* temperature_dev, 
 int c4_sample_move(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, const float* policy_dev,
                    const float* temperature_dev, uint64_t n, int32_t* out_col_dev, uint32_t* out_u32_dev, void* stream);
 
+/* ---- evaluator building block: the residual conv tower of ConnectFourNet (src/c4a0/nn.py:64-70,
+ * 184-195; eval-mode BatchNorm folded into the second conv of each block) as one MFMA kernel.
+ *   planes_dev bf16 [n_boards][2][6][7] (what c4_session_step writes with planes_dtype = 1)
+ *   w0_dev / w_dev / bias_dev: MFMA-fragment-ordered weights, see c4a0_amd/nn.py::pack_tower_weights
+ *   out_dev    bf16 [n_boards][42][channels]  (cell-major, channels last)
+ * channels must be 32 or 64. */
+int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w_dev, const float* bias_dev,
+                       uint32_t n_boards, uint32_t channels, uint32_t n_blocks, void* out_dev, void* stream);
+
+/* Output layers of both heads in one launch (nn.py:84-85,98-99): policy Linear(F->7) + LogSoftmax
+ * and value Linear(F->2) + Tanh.  hidden_*_dev bf16 [n_boards][features] (the last hidden
+ * activation of each head; the same pointer twice when a head has no hidden layer), w_* bf16
+ * [7|2][features], b_* f32; writes logprobs_dev f32 [n_boards][7] and q_dev f32 [n_boards][2]
+ * (the tensors bound with c4_session_bind_io).  features % 8 == 0. */
+int c4_head_out_bf16(const void* hidden_policy_dev, const void* hidden_value_dev, const void* w_policy_dev,
+                     const void* w_value_dev, const float* b_policy_dev, const float* b_value_dev,
+                     uint32_t n_boards, uint32_t features, float* logprobs_dev, float* q_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

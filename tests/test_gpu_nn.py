@@ -1,0 +1,114 @@
+"""GPU checks of the evaluator: the hand-written MFMA conv tower and the bf16 inference net
+against a plain PyTorch fp32 reference of the same op (floating point => tolerance, stated)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _positions(n, seed=3):
+    from tests.helpers import random_positions
+
+    pos = random_positions(n, seed=seed)
+    pl = np.zeros((n, 2, 42), dtype=np.float32)
+    for i, (m, v) in enumerate(pos):
+        for b in range(42):
+            pl[i, 0, b] = (v >> b) & 1
+            pl[i, 1, b] = ((m & ~v) >> b) & 1
+    return torch.from_numpy(pl.reshape(n, 2, 6, 7))
+
+
+def _ref_tower(model, x):
+    """fp32 reference with the SAME bf16-rounded weights (so only accumulation/rounding of
+    activations differs)."""
+    import torch.nn.functional as F
+    from c4a0_amd.nn import _fold_bn
+
+    r = lambda t: t.detach().float().bfloat16().float()
+    conv0 = model.conv[0]
+    y = F.conv2d(x, r(conv0.weight), conv0.bias.detach().float(), padding=1)
+    for blk in list(model.conv)[1:]:
+        c1, c2, bn = blk.block[0], blk.block[1], blk.block[2]
+        w2, b2 = _fold_bn(c2.weight, c2.bias, bn)
+        t = F.conv2d(y, r(c1.weight), c1.bias.detach().float(), padding=1)
+        t = F.conv2d(t, r(w2), b2, padding=1)
+        y = y + F.relu(t)
+    return y
+
+
+@pytest.mark.parametrize("channels,blocks,n", [(32, 1, 37), (32, 4, 4096), (64, 2, 100), (64, 8, 512)])
+def test_hip_conv_tower_vs_fp32_reference(channels, blocks, n):
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(channels + blocks)
+    model = ConnectFourNet(ModelConfig(blocks, channels, 2, 2)).eval()
+    g = torch.Generator().manual_seed(5)
+    for m in model.modules():  # non-trivial BN statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+    x = _positions(n)
+    net = InferenceNet(model, dev, dtype=torch.bfloat16, hip_tower=True)
+    got = net.tower(x.to(dev).bfloat16()).float().cpu().reshape(n, 42, channels).permute(0, 2, 1).reshape(n, channels, 6, 7)
+    with torch.no_grad():
+        want = _ref_tower(model, x)
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item()
+    # bf16 activations between layers: 8 bits of mantissa per layer, 1 + 2*blocks layers
+    assert err <= 0.02 * scale * (1 + blocks) ** 0.5, (err, scale)
+    # and it is not trivially zero / permuted: correlation with the reference
+    assert torch.corrcoef(torch.stack([got.flatten(), want.flatten()]))[0, 1] > 0.999
+
+
+def test_inference_net_hip_vs_torch_paths_and_reference_fixture():
+    """Whole evaluator on the device: HIP-tower path vs PyTorch-conv path vs fp32 module."""
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1337)
+    model = ConnectFourNet(ModelConfig(4, 32, 4, 2)).eval()
+    x = _positions(777, seed=9)
+    with torch.no_grad():
+        lp_ref, qp_ref, qn_ref = model(x)
+    for tower in (True, False):
+        net = InferenceNet(model, dev, dtype=torch.bfloat16, hip_tower=tower)
+        lp, q = net(x.to(dev).bfloat16())
+        lp, q = lp.cpu(), q.cpu()
+        assert lp.dtype == torch.float32 and q.shape == (777, 2)
+        assert (lp - lp_ref).abs().max() < 0.05, (tower, (lp - lp_ref).abs().max())     # bf16 weights + activations
+        assert (q[:, 0] - qp_ref).abs().max() < 0.05 and (q[:, 1] - qn_ref).abs().max() < 0.05
+        assert torch.allclose(lp.exp().sum(1), torch.ones(777), atol=1e-4)
+
+
+def test_graphed_evaluator_matches_eager_and_drives_a_session():
+    from c4a0_amd.nn import ConnectFourNet, GraphedEvaluator, InferenceNet, ModelConfig
+    from c4a0_amd.session import DeviceSession
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 2, 2)), dev, dtype=torch.bfloat16)
+    s = DeviceSession(64, 8, 6.6, 0.01, device=dev, planes_dtype=torch.bfloat16)
+    s.set_games([(i, 0, 0) for i in range(100)])
+    s.bind()
+    s.start()
+    ge = GraphedEvaluator(net, s.planes, s.logprobs, s.q)
+    for _ in range(5):
+        s.evaluate(ge)
+        lp_e, q_e = net(s.planes)
+        assert torch.equal(lp_e, s.logprobs) and torch.equal(q_e, s.q)
+        s.step()
+    steps = 5
+    while s.counters()["games_done"] < 100 and steps < 20000:
+        for _ in range(64):
+            s.evaluate(ge)
+            s.step()
+        steps += 64
+    c = s.counters()
+    assert c["games_done"] == 100 and c["error"] == 0
+    recs = s.drain_samples()
+    assert len(recs) == c["samples"] and set(np.unique(recs["game_id"]).tolist()) == set(range(100))
+    s.close()
