@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libc4a0_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("C4A0_HIP_LIB", "libc4a0_hip.so"))  # C4A0_HIP_LIB: diagnostic builds
 
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NAN_IN_TREE, ERR_DEGENERATE_POLICY, ERR_ARENA_OVERFLOW, ERR_NOT_BOUND, ERR_NO_DEVICE, ERR_ILLEGAL_MOVE = range(9)
 STATUS_NAMES = {
@@ -43,7 +43,7 @@ class Config(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("sims", "select_levels", "backup_nodes", "expansions", "moves", "games_done",
-                                          "ref_skipped_sims", "samples", "games_started")] + \
+                                          "ref_skipped_sims", "samples", "games_started", "step_kernel_ns", "step_launches")] + \
                [("error", C.c_uint32), ("error_slot", C.c_uint32)]
 
     def as_dict(self):
@@ -67,6 +67,7 @@ SIGNATURES = {
     "c4_session_sample_counts": (C.c_int, [_vp, _P(C.c_uint32), C.c_uint64]),
     "c4_session_drain_samples": (C.c_int, [_vp, _P(SampleRec), C.c_uint64, _P(C.c_uint64)]),
     "c4_session_pack_samples": (C.c_int, [_vp, _vp, C.c_uint64, _P(C.c_uint64)]),
+    "c4_session_debug_phase_stamps": (C.c_int, [_vp, _P(C.c_uint64), C.c_uint64, _P(C.c_uint64)]),
     "c4_session_sample_store": (C.c_int, [_vp, _P(_vp), _P(_vp), _P(C.c_uint64)]),
     "c4_session_root_stats": (C.c_int, [_vp, C.c_uint32, _P(C.c_float), _P(C.c_float), _P(C.c_float),
                                         _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint64)]),

@@ -19,11 +19,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    """diag=True builds libc4a0_hip_diag.so with in-kernel phase stamps (tools/phase_profile.py)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    stale = force or not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in DEPS)
+    out = OUT.replace(".so", "_diag.so") if diag else OUT
+    stale = force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in DEPS)
     if stale:
-        cmd = [hipcc] + FLAGS + SRCS + ["-o", OUT]
+        cmd = [hipcc] + FLAGS + (["-DC4_PHASE_STAMPS"] if diag else []) + SRCS + ["-o", out]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -31,8 +33,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
         if verbose and r.stderr:
             print(r.stderr)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

@@ -256,6 +256,61 @@ C4_DEV int weighted_index(const float* w, uint32_t u) {
   return idx;
 }
 
+// ------------------------------------------------------------------------------------------
+// 8-lane-group versions used by the step kernel's move phase: same arithmetic, spread over the
+// lanes of one game (`sub` = lane within the group, `gbase` = first lane of the group).
+// ------------------------------------------------------------------------------------------
+C4_DEV float grp_shfl(float v, int src) { return __shfl(v, src, 64); }
+C4_DEV uint32_t grp_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+
+// mcts.rs:439-454: lane c < 7 evaluates column c; sums run left to right over broadcast values,
+// exactly as the scalar version.  Every lane returns the full out[7].
+C4_DEV void apply_temperature_group(const float* p, float t, float* out, uint32_t sub, int gbase) {
+  bool all_eq = true;
+  for (int i = 0; i < 7; i++) all_eq = all_eq && (p[i] == p[0]);
+  if (t == 1.0f || all_eq || t == 0.0f) {  // the cheap branches stay scalar
+    apply_temperature(p, t, out);
+    return;
+  }
+  const float mine = p[sub < 7 ? sub : 6];
+  const float pl = c4_logf(mine) / t;
+  const float ex = c4_expf(pl);
+  float s = 0.0f;
+  for (int i = 0; i < 7; i++) s = s + grp_shfl(ex, gbase + i);
+  const float lse = c4_logf(s);
+  float v = c4_expf(pl - lse);
+  if (v < 0.0f) v = 0.0f;
+  if (v > 1.0f) v = 1.0f;
+  for (int i = 0; i < 7; i++) out[i] = grp_shfl(v, gbase + i);
+}
+
+// rng_first_u32 with the ChaCha state spread over lanes 0..3 of the group: lane i holds column i
+// (x_i, x_{4+i}, x_{8+i}, x_{12+i}); a column round is lane-local, a diagonal round rotates rows
+// b, c, d by 1, 2, 3 lanes.  Lanes 4..7 compute along harmlessly.
+C4_DEV uint32_t rng_first_u32_group(uint64_t state, uint32_t sub, int gbase) {
+  const uint64_t MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
+  const uint32_t i = sub & 3;
+  uint32_t kb = 0, kc = 0;  // key words k[i] (row b) and k[4+i] (row c)
+  for (uint32_t w = 0; w < 8; w++) {
+    state = state * MUL + INC;
+    const uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27);
+    const uint32_t rot = (uint32_t)(state >> 59);
+    const uint32_t k = (xs >> rot) | (xs << ((32 - rot) & 31));
+    kb = (w == i) ? k : kb;
+    kc = (w == 4 + i) ? k : kc;
+  }
+  const uint32_t c0 = i == 0 ? 0x61707865u : (i == 1 ? 0x3320646eu : (i == 2 ? 0x79622d32u : 0x6b206574u));
+  uint32_t a = c0, b = kb, c = kc, d = 0;
+  const int l1 = gbase + (int)((i + 1) & 3), l2 = gbase + (int)((i + 2) & 3), l3 = gbase + (int)((i + 3) & 3);
+  for (int r = 0; r < 6; r++) {
+    C4_QR(a, b, c, d)
+    b = grp_shfl(b, l1); c = grp_shfl(c, l2); d = grp_shfl(d, l3);   // diagonals: (x0,x5,x10,x15) ...
+    C4_QR(a, b, c, d)
+    b = grp_shfl(b, l3); c = grp_shfl(c, l2); d = grp_shfl(d, l1);   // back to columns
+  }
+  return grp_shfl(a, gbase) + 0x61707865u;  // word 0 = column 0's `a` + its constant
+}
+
 // self_play.rs:294-299
 C4_DEV float temperature_for_ply(uint32_t ply) { return ply < 4 ? 4.0f : (ply < 8 ? 2.0f : 1.0f); }
 

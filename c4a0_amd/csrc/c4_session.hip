@@ -65,13 +65,27 @@ struct __attribute__((aligned(256))) Slot {
   uint32_t depth;       // leaf depth below the root; path[depth] = the leaf's entry
   uint32_t n_blocks;    // bump pointer of this slot's arena
   uint32_t n_moves;     // MctsGame::moves.len()
-  uint32_t pad[2];
+  uint32_t leaf_ref;    // = path[depth], kept in the header so the first line carries it
+  uint32_t pad;
   uint32_t path[kMaxPath];  // entry refs root..leaf written by select, consumed by backup
 };
 static_assert(sizeof(Slot) == 256, "slot state is two cache lines");
 static_assert(sizeof(Block) == 128 && sizeof(QRow) == 32 && sizeof(c4_sample_rec) == 64, "layout");
 
 enum : uint32_t { kIdle = 0, kActive = 1 };
+
+// Diagnostic build only (-DC4_PHASE_STAMPS, tools/phase_profile.py): per-wavefront device-clock
+// stamps at the phase boundaries of the step kernel.  `force` makes the stamp wait for the values
+// the phase produced.  Never compiled into libc4a0_hip.so.
+#ifdef C4_PHASE_STAMPS
+#define C4_STAMP(i, force)                                                                          \
+  do {                                                                                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                       \
+    if (lane == 0) p.phase[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime() + ((force) & 0);  \
+  } while (0)
+#else
+#define C4_STAMP(i, force) do { } while (0)
+#endif
 enum : int { CTR_SIMS = 0, CTR_S, CTR_K, CTR_E, CTR_MOVES, CTR_DONE, CTR_SKIPPED, CTR_SAMPLES, CTR_N };
 
 struct Globals {             // one small device struct of cross-wave words
@@ -86,6 +100,11 @@ struct Params {
   Block* blocks;
   QRow* qrows;
   unsigned long long* wave_ctr;  // [n_waves][CTR_N]
+  unsigned long long* stamps;    // [2][n_waves][2] start/end device clock of each wavefront, by launch parity
+  unsigned long long* clock_acc; // [2] sum of (last end - first start) over launches, number of launches summed
+  uint32_t n_waves;
+  uint32_t seq;                  // launch sequence number
+  unsigned long long* phase;     // diagnostic build: [n_waves][16] phase stamps of the last launch
   Globals* glob;
   const c4_game_metadata* reqs;
   const uint64_t* start_mask;    // may be null
@@ -143,6 +162,7 @@ C4_DEV void reset_slot(const Params& p, Slot* st, Block* blocks, QRow* qrows, ui
     st->status = kActive;
     st->root_ref = 0; st->root_block = 0; st->root_n = 0;
     st->depth = 0; st->n_blocks = 1; st->n_moves = 0;
+    st->leaf_ref = 0;
     st->path[0] = 0;
   }
 }
@@ -185,8 +205,35 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
   const uint32_t g = blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
 
   unsigned long long c_sims = 0, c_S = 0, c_K = 0, c_E = 0, c_moves = 0, c_done = 0, c_skipped = 0, c_samples = 0;
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz device clock
+  C4_STAMP(0, 0);
+#ifdef C4_PHASE_STAMPS
+  if (lane == 0) for (int i = 9; i < 16; i++) p.phase[(size_t)blockIdx.x * 16 + i] = 0;
+#endif
+  if (blockIdx.x == 0 && p.seq > 0) {
+    // duration of the PREVIOUS launch = last wavefront end - first wavefront start (its stamps are
+    // complete: kernel boundary); one writer, no atomics
+    const unsigned long long* prev = p.stamps + (size_t)((p.seq - 1) & 1) * p.n_waves * 2;
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (uint32_t w = lane; w < p.n_waves; w += 64) {
+      const unsigned long long a = prev[2 * w], b = prev[2 * w + 1];
+      lo = a < lo ? a : lo;
+      hi = b > hi ? b : hi;
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long ol = ((unsigned long long)shfl_u32((uint32_t)(lo >> 32), (int)(lane ^ off)) << 32) | shfl_u32((uint32_t)lo, (int)(lane ^ off));
+      const unsigned long long oh = ((unsigned long long)shfl_u32((uint32_t)(hi >> 32), (int)(lane ^ off)) << 32) | shfl_u32((uint32_t)hi, (int)(lane ^ off));
+      lo = ol < lo ? ol : lo;
+      hi = oh > hi ? oh : hi;
+    }
+    if (lane == 0 && hi > lo) { p.clock_acc[0] += hi - lo; p.clock_acc[1] += 1; }
+  }
 
-  Slot* st = p.slots + (g < p.n_slots ? g : 0);
+  const uint32_t gs = g < p.n_slots ? g : 0;
+  Slot* st = p.slots + gs;
+  // evaluator outputs of this game: issued first so they travel with the slot header
+  const float nn_logit = p.logprobs[(size_t)gs * 7 + (sub < 7 ? sub : 6)];
+  const float nn_q = p.q[(size_t)gs * 2 + (sub & 1)];
   bool active = (g < p.n_slots) && (st->status == kActive);
 
   if (active) {
@@ -200,9 +247,14 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     uint32_t root_ref = st->root_ref;
     uint32_t root_block = st->root_block;
     uint32_t n_moves = st->n_moves;
-    const uint32_t leaf_ref = st->path[depth];
+    const uint32_t leaf_ref = st->leaf_ref;
+    // path entries of this lane's backup levels (sub, sub+8): addresses do not depend on `depth`,
+    // so these loads go out together with the header
+    const uint32_t path_a = st->path[sub];
+    const uint32_t path_b = st->path[sub + 8];
     uint32_t err = 0;
 
+    C4_STAMP(1, depth + n_blocks + leaf_ref + path_a + path_b + (uint32_t)leaf_mask);
     // ---------------- on_received_policy: terminal value or expansion -------------------
     float v_pen, v_nopen;
     const uint32_t term = c4::terminal_state(leaf_mask, leaf_value);
@@ -212,7 +264,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       const uint32_t legal = c4::legal_mask(leaf_mask);
       const bool is_legal = sub < 7 && ((legal >> sub) & 1u);
       float logit = __uint_as_float(0xff800000u);                             // mask_policy, c4r.rs:272-286
-      if (is_legal) logit = p.logprobs[(size_t)g * 7 + sub];
+      if (is_legal) logit = nn_logit;
       float mx = logit;                                                       // f32::max fold (NaN-ignoring)
       mx = c4::rust_max(mx, shfl_f32(mx, (int)(lane ^ 1)));
       mx = c4::rust_max(mx, shfl_f32(mx, (int)(lane ^ 2)));
@@ -237,17 +289,18 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
         n_blocks = nb + 1;
         c_E = 1;
       }
-      v_pen = p.q[(size_t)g * 2 + 0];
-      v_nopen = p.q[(size_t)g * 2 + 1];
+      v_pen = shfl_f32(nn_q, gbase);
+      v_nopen = shfl_f32(nn_q, gbase + 1);
     }
 
     if (err) {
       if (sub == 0) raise_error(p, st, g, err);
     } else {
+      C4_STAMP(2, n_blocks);
       // ---------------- backpropagate_value: leaf -> root along the recorded path ----------
       uint32_t root_n = 0;
       for (uint32_t d = sub; d <= depth; d += 8) {
-        const uint32_t ref = st->path[d];
+        const uint32_t ref = (d < 8) ? path_a : (d < 16 ? path_b : st->path[d]);
         Entry* e = &blocks[ref >> 3].e[ref & 7];
         float* qn = &qrows[ref >> 3].q_nopen[ref & 7];
         const bool odd = ((depth - d) & 1u) != 0;                             // value negated per step up
@@ -263,7 +316,9 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       c_sims = 1;
       c_K = depth + 1;
       // stores above are read back below through other lanes of this wave
+      C4_STAMP(3, root_n);
       __threadfence_block();
+      C4_STAMP(4, root_n);
 
       // ---------------- gate: self_play.rs:283-308 ------------------------------------------
       bool finished = false;
@@ -280,12 +335,16 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
           for (int i = 0; i < 7; i++) { w[i] = shfl_f32(cnt, gbase + i); csum = csum + w[i]; }
           float pol[7];
           for (int i = 0; i < 7; i++) pol[i] = (csum == 0.0f) ? (1.0f / 7.0f) : (w[i] / csum);
-          // make_random_move (mcts.rs:214-222)
+          // make_random_move (mcts.rs:214-222); the 7 columns' logf/expf and the 4 ChaCha columns
+          // run on the game's own lanes instead of 8 redundant copies
           const float temperature = c4::temperature_for_ply((uint32_t)__popcll(rmask));
+          C4_STAMP(9, (uint32_t)pol[0]);
           float tp[7];
-          c4::apply_temperature(pol, temperature, tp);
+          c4::apply_temperature_group(pol, temperature, tp, sub, gbase);
+          C4_STAMP(10, (uint32_t)tp[0]);
           const uint64_t seed = st->game_id * (uint64_t)(42 + n_moves);
-          const int col = c4::weighted_index(tp, c4::rng_first_u32(seed));
+          const int col = c4::weighted_index(tp, c4::rng_first_u32_group(seed, sub, gbase));
+          C4_STAMP(11, (uint32_t)col);
           if (col < 0) {
             err = C4_ERR_DEGENERATE_POLICY;
           } else if (!((c4::legal_mask(rmask) >> col) & 1u)) {
@@ -338,6 +397,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       if (err) {
         if (sub == 0) raise_error(p, st, g, err);
       } else {
+        C4_STAMP(12, root_n);
         if (finished) {
           // replace the finished game by the next one of the request list (keeps the batch full)
           unsigned long long next = 0;
@@ -358,9 +418,10 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
           }
         }
         if (active) {
+          C4_STAMP(5, root_n);
           // ---------------- select_new_leaf (mcts.rs:160-183) -------------------------------
           uint64_t m = rmask, v = rvalue;
-          uint32_t blk = root_block, np = root_n, d = 0;
+          uint32_t blk = root_block, np = root_n, d = 0, last_ref = root_ref;
           while (blk != 0 && d + 1 < kMaxPath) {
             const Entry ce = blocks[blk].e[sub];
             const uint32_t legal = c4::legal_mask(m);
@@ -392,7 +453,8 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
             const uint32_t next_blk = shfl_u32(ce.child, gbase + (int)best);
             c4::make_move(m, v, best);
             d += 1;
-            if (sub == 0) st->path[d] = (blk << 3) | best;
+            last_ref = (blk << 3) | best;
+            if (sub == 0) st->path[d] = last_ref;
             blk = next_blk;
             c_S += 1;
           }
@@ -405,7 +467,9 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
               st->root_ref = root_ref; st->root_block = root_block; st->root_n = root_n;
               st->depth = d; st->n_blocks = n_blocks; st->n_moves = n_moves;
               st->path[0] = root_ref;
+              st->leaf_ref = last_ref;
             }
+            C4_STAMP(6, d);
             // ---------------- leaf -> evaluator input (c4r.rs:378-392) ----------------------
             for (uint32_t e = sub; e < C4_PLANES_LEN; e += 8)
               store_plane<PlaneT>(p.planes, (size_t)g * C4_PLANES_LEN + e, c4::plane_bit(m, v, e));
@@ -415,21 +479,26 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     }
   }
 
+  C4_STAMP(7, 0);
   // ---------------- per-wavefront counters (one writer per row: no atomics) -----------------
-  unsigned long long vals[CTR_N] = {c_sims, c_S, c_K, c_E, c_moves, c_done, c_skipped, c_samples};
-  for (int k = 0; k < CTR_N; k++) {
-    unsigned long long x = vals[k];  // uniform within a game's 8 lanes: summing lanes l, l^8, l^16, l^32 adds the 8 games
-    for (int off = 8; off < 64; off <<= 1) {
-      const uint32_t lo = shfl_u32((uint32_t)x, (int)(lane ^ off));
-      const uint32_t hi = shfl_u32((uint32_t)(x >> 32), (int)(lane ^ off));
-      x += ((unsigned long long)hi << 32) | lo;
-    }
-    vals[k] = x;
+  // lane `sub` of each game adds that game's counter number `sub` to the wavefront's row: one
+  // no-return atomic instruction for the whole wave (nobody waits for it; rows have one writer wave)
+  {
+    unsigned long long add = c_sims;
+    add = sub == CTR_S ? c_S : add;
+    add = sub == CTR_K ? c_K : add;
+    add = sub == CTR_E ? c_E : add;
+    add = sub == CTR_MOVES ? c_moves : add;
+    add = sub == CTR_DONE ? c_done : add;
+    add = sub == CTR_SKIPPED ? c_skipped : add;
+    add = sub == CTR_SAMPLES ? c_samples : add;
+    if (add) atomicAdd(&p.wave_ctr[(size_t)blockIdx.x * CTR_N + sub], add);
   }
-  if (lane < CTR_N) {
-    unsigned long long add = 0;
-    for (int k = 0; k < CTR_N; k++) add = (lane == (uint32_t)k) ? vals[k] : add;
-    if (add) p.wave_ctr[(size_t)blockIdx.x * CTR_N + lane] += add;
+  C4_STAMP(8, 0);
+  if (lane == 0) {
+    unsigned long long* my = p.stamps + ((size_t)(p.seq & 1) * p.n_waves + blockIdx.x) * 2;
+    my[0] = t_start;
+    my[1] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -542,6 +611,7 @@ struct c4_session {
   Params p{};
   hipStream_t stream = nullptr;
   uint32_t n_waves = 0;
+  uint32_t seq = 0;
   bool bound = false, have_games = false;
   uint64_t n_games = 0;
   c4_game_metadata* reqs_dev = nullptr;
@@ -597,6 +667,9 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
       (e = hipMalloc(&p.qrows, n * bps * sizeof(QRow))) != hipSuccess ||
       (e = hipMalloc(&p.wave_ctr, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.glob, sizeof(Globals))) != hipSuccess ||
+      (e = hipMalloc(&p.stamps, (size_t)s->n_waves * 4 * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMalloc(&p.clock_acc, 2 * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMalloc(&p.phase, (size_t)s->n_waves * 16 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipHostMalloc(&s->probe_host, sizeof(Globals))) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s->probe_event, hipEventDisableTiming)) != hipSuccess) {
     std::string msg = std::string("allocating session (") + std::to_string((n * bps * (sizeof(Block) + sizeof(QRow))) >> 20) +
@@ -604,6 +677,10 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
     c4_session_destroy(s);
     return fail(C4_ERR_HIP, msg);
   }
+  p.n_waves = s->n_waves;
+  HIP_TRY(hipMemset(p.stamps, 0, (size_t)s->n_waves * 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(p.clock_acc, 0, 2 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(p.phase, 0, (size_t)s->n_waves * 16 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(p.slots, 0, n * sizeof(Slot)));
   HIP_TRY(hipMemset(p.glob, 0, sizeof(Globals)));
   HIP_TRY(hipMemset(p.wave_ctr, 0, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long)));
@@ -616,7 +693,7 @@ int c4_session_destroy(c4_session* s) {
   if (!s) return C4_OK;
   (void)hipSetDevice(s->cfg.device);
   if (s->stream) (void)hipStreamSynchronize(s->stream); else (void)hipDeviceSynchronize();
-  (void)hipFree(s->p.slots); (void)hipFree(s->p.blocks); (void)hipFree(s->p.qrows); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob);
+  (void)hipFree(s->p.slots); (void)hipFree(s->p.blocks); (void)hipFree(s->p.qrows); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob); (void)hipFree(s->p.stamps); (void)hipFree(s->p.clock_acc); (void)hipFree(s->p.phase);
   (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts);
   (void)hipFree(s->reqs_dev); (void)hipFree(s->start_mask_dev); (void)hipFree(s->start_value_dev);
   if (s->probe_host) (void)hipHostFree(s->probe_host);
@@ -658,6 +735,9 @@ int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n
   s->p.n_games = n_games;
   s->n_games = n_games;
   s->have_games = true;
+  HIP_TRY(hipMemset(s->p.stamps, 0, (size_t)s->n_waves * 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(s->p.clock_acc, 0, 2 * sizeof(unsigned long long)));
+  s->seq = 0;
   s->probe_pending = false; s->probe_done = 0; s->probe_error = 0;
   return C4_OK;
 }
@@ -687,6 +767,7 @@ int c4_session_start(c4_session* s) {
 int c4_session_step(c4_session* s) {
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
   if (!s->bound || !s->have_games) return fail(C4_ERR_NOT_BOUND, "bind_io and set_games must precede step");
+  s->p.seq = s->seq++;
   if (s->cfg.planes_dtype == 0)
     hipLaunchKernelGGL(c4_step_kernel<float>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
   else
@@ -712,6 +793,19 @@ int c4_session_counters(c4_session* s, c4_counters* out) {
   out->ref_skipped_sims = sum[CTR_SKIPPED]; out->samples = sum[CTR_SAMPLES];
   out->games_started = g.queue_head < s->n_games ? g.queue_head : s->n_games;
   out->error = g.error; out->error_slot = g.error_slot;
+  // device-clock time of the step kernel: launches already folded in by the following launch,
+  // plus the last one from its raw stamps
+  unsigned long long acc[2] = {0, 0};
+  HIP_TRY(hipMemcpy(acc, s->p.clock_acc, sizeof acc, hipMemcpyDeviceToHost));
+  if (s->seq > 0) {
+    std::vector<unsigned long long> st((size_t)s->n_waves * 2);
+    HIP_TRY(hipMemcpy(st.data(), s->p.stamps + (size_t)((s->seq - 1) & 1) * s->n_waves * 2, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (size_t w = 0; w < s->n_waves; w++) { if (st[2 * w] < lo) lo = st[2 * w]; if (st[2 * w + 1] > hi) hi = st[2 * w + 1]; }
+    if (hi > lo) { acc[0] += hi - lo; acc[1] += 1; }
+  }
+  out->step_kernel_ns = acc[0] * 10ull;  // s_memrealtime ticks at 100 MHz
+  out->step_launches = acc[1];
   return C4_OK;
 }
 
@@ -792,6 +886,17 @@ int c4_session_pack_samples(c4_session* s, c4_sample_rec* dst_dev, uint64_t cap,
   }
   (void)hipFree(offs_dev);
   if (e != hipSuccess) return fail(C4_ERR_HIP, std::string("pack_samples: ") + hipGetErrorString(e));
+  return C4_OK;
+}
+
+// diagnostic builds only: raw phase stamps [n_waves][16] of the last launch (zeros otherwise)
+int c4_session_debug_phase_stamps(c4_session* s, uint64_t* out_host, uint64_t cap_words, uint64_t* n_words) {
+  if (!s || !n_words) return fail(C4_ERR_BAD_ARG, "null argument");
+  *n_words = (uint64_t)s->n_waves * 16;
+  if (!out_host) return C4_OK;
+  if (cap_words < *n_words) return fail(C4_ERR_BAD_ARG, "destination too small");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(out_host, s->p.phase, *n_words * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return C4_OK;
 }
 

@@ -87,6 +87,9 @@ typedef struct {
   uint64_t ref_skipped_sims;/* terminal-root sims the reference would still run (self_play.rs:283-301) */
   uint64_t samples;
   uint64_t games_started;
+  uint64_t step_kernel_ns;  /* device-clock time inside c4_session_step's kernel, summed over launches:
+                               last wavefront end - first wavefront start (s_memrealtime, 10 ns ticks) */
+  uint64_t step_launches;   /* launches summed in step_kernel_ns */
   uint32_t error;           /* first c4_status raised on the device, 0 = none */
   uint32_t error_slot;
 } c4_counters;
@@ -142,6 +145,9 @@ int c4_session_drain_samples(c4_session* s, c4_sample_rec* dst_host, uint64_t ca
  * contiguous tensor for the RCCL all-gather.  *n_written = records packed.  Synchronises (the
  * per-game counts are prefix-summed on the host). */
 int c4_session_pack_samples(c4_session* s, c4_sample_rec* dst_dev, uint64_t cap, uint64_t* n_written);
+/* Diagnostic builds (-DC4_PHASE_STAMPS) only: per-wavefront device-clock stamps [n_waves][16] of the
+ * last step launch; all zero in the product build. */
+int c4_session_debug_phase_stamps(c4_session* s, uint64_t* out_host, uint64_t cap_words, uint64_t* n_words);
 /* Device views for collectives (RCCL all-gather of samples): records [n_games][43], counts [n_games]. */
 int c4_session_sample_store(c4_session* s, const c4_sample_rec** recs_dev, const uint32_t** counts_dev, uint64_t* n_games);
 
