@@ -23,6 +23,7 @@
 //     two tiles are in flight per wave so consecutive MFMAs never wait on their accumulator.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <string>
 
@@ -64,8 +65,157 @@ struct TowerParams {
   uint32_t n_blocks;
 };
 
-template <int C, int NB>
-__global__ __launch_bounds__(256) void c4_conv_tower_kernel(TowerParams p) {
+// One conv layer for this wavefront's tiles.  kConv0: the 2-channel input layer (3 k-steps whose
+// k-groups are taps); otherwise a C -> C layer (9 taps x C/32 k-steps).
+//
+// Schedule per wavefront (one wave per SIMD, so nothing else hides latency):
+//   * a "pair" = two tiles in flight = 2 x MT independent accumulators;
+//   * the B fragments of pair i+1 are requested from LDS before pair i's MFMAs;
+//   * the epilogue of pair i-1 (ReLU, residual, bf16 pack, LDS store: VALU + LDS work) is emitted
+//     in the same scheduling region as pair i's MFMAs so it fills the MFMA issue gaps;
+//   * the accumulators start at the bias;
+//   * the NEXT layer's weights are requested right after this layer's last MFMA, under the last
+//     epilogue and the barrier.
+template <int C, int NB, bool kConv0, int MODE, int TPP, typename WF, typename NextW>
+__device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4* __restrict__ dst, WF& wf,
+                                            const float* __restrict__ bias, bool is_second, int tile_lo, int tile_hi,
+                                            int lane, NextW&& load_next_weights) {
+  using G = Geo<C, NB>;
+  constexpr int kSteps = kConv0 ? 3 : 9 * G::KC;        // MFMA k-steps (= B fragments) per tile
+  constexpr bool kDouble = (MODE == 1);                 // double-buffered fragments + overlapped epilogue
+  const int li = lane & 15, lg = lane >> 4;
+
+  f32x4 bias4[G::MT];
+#pragma unroll
+  for (int m = 0; m < G::MT; m++) {
+    const float* bp = bias + 16 * m + 4 * lg;
+    bias4[m] = f32x4{bp[0], bp[1], bp[2], bp[3]};
+  }
+
+  struct Pair {
+    f32x4 acc[TPP][G::MT];
+    int bidx[TPP], slot[TPP];
+    bool two, live;
+  };
+  auto geom = [&](int tile, Pair& pr) __attribute__((always_inline)) {
+    pr.live = tile < tile_hi;
+    pr.two = tile + 1 < tile_hi;
+#pragma unroll
+    for (int u = 0; u < TPP; u++) {
+      const int tl = (u == 1 && !pr.two) ? tile : tile + u;
+      pr.bidx[u] = tl / kTilesPerBoard;
+      pr.slot[u] = 9 + 16 * (tl - pr.bidx[u] * kTilesPerBoard) + li;   // cell_slot of the tile's first cell is 9 + 16 j
+    }
+  };
+  auto load_frags = [&](const Pair& pr, uint4 (&fr)[TPP][kSteps]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < kSteps; k++) {
+      int d, plane;
+      if (kConv0) {
+        // k-step k, k-group lg <-> tap 4 k + lg (taps >= 9 have zero weights); the input image is
+        // channel group 0: 8 "channels" per cell, 2 real
+        int tap = 4 * k + lg;
+        tap = tap < 9 ? tap : 4;
+        d = 8 * (tap / 3 - 1) + (tap % 3 - 1);
+        plane = 0;
+      } else {
+        const int t = k / G::KC, kc = k % G::KC;
+        d = 8 * (t / 3 - 1) + (t % 3 - 1);
+        plane = 4 * kc + lg;
+      }
+#pragma unroll
+      for (int u = 0; u < TPP; u++) fr[u][k] = src[(plane * NB + pr.bidx[u]) * kPCS + pr.slot[u] + d];
+    }
+  };
+  auto mfmas = [&](Pair& pr, const uint4 (&fr)[TPP][kSteps]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < TPP; u++)
+#pragma unroll
+      for (int m = 0; m < G::MT; m++) pr.acc[u][m] = bias4[m];
+#pragma unroll
+    for (int k = 0; k < kSteps; k++)
+#pragma unroll
+      for (int u = 0; u < TPP; u++)
+#pragma unroll
+        for (int m = 0; m < G::MT; m++)
+          pr.acc[u][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k][m], __builtin_bit_cast(bf16x8, fr[u][k]), pr.acc[u][m], 0, 0, 0);
+  };
+  // lane holds output channels 16 m + 4 lg + {0..3} of cell `slot`
+  auto epilogue = [&](const Pair& pr) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < TPP; u++) {
+      const bool valid = (((pr.slot[u] - 1) & 7) != 0) && (u == 0 || pr.two);   // padded column 0 is halo
+      if (valid) {
+#pragma unroll
+        for (int m = 0; m < G::MT; m++) {
+          f32x4 v = pr.acc[u][m];
+          // 8-byte half of the 16-byte slot of channel group 2 m + lg/2
+          uint2* dp = reinterpret_cast<uint2*>(&dst[((2 * m + (lg >> 1)) * NB + pr.bidx[u]) * kPCS + pr.slot[u]]) + (lg & 1);
+          if (is_second) {
+            const uint2 old = *dp;   // bf16 x4: widen by shifting into the f32 exponent/mantissa
+            const float o0 = __uint_as_float(old.x << 16), o1 = __uint_as_float(old.x & 0xffff0000u);
+            const float o2 = __uint_as_float(old.y << 16), o3 = __uint_as_float(old.y & 0xffff0000u);
+            v[0] = o0 + fmaxf(v[0], 0.f); v[1] = o1 + fmaxf(v[1], 0.f);
+            v[2] = o2 + fmaxf(v[2], 0.f); v[3] = o3 + fmaxf(v[3], 0.f);
+          }
+          const bf16x4 o = __builtin_convertvector(v, bf16x4);
+          *dp = __builtin_bit_cast(uint2, o);
+        }
+      }
+    }
+  };
+
+  if constexpr (kDouble) {
+    uint4 f0[TPP][kSteps], f1[TPP][kSteps];
+    Pair pa, pb;
+    geom(tile_lo, pa);
+    pb.live = false;
+    if (pa.live) load_frags(pa, f0);
+    for (int tile = tile_lo; tile < tile_hi; tile += 2 * TPP) {
+      // --- pair A = tiles (tile, tile+1); pair B of the previous round still needs its epilogue
+      Pair pb_prev = pb;
+      geom(tile + TPP, pb);
+      if (pb.live) load_frags(pb, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(pa, f0);
+      if (pb_prev.live) epilogue(pb_prev);
+      __builtin_amdgcn_sched_barrier(0);
+      // --- pair B = tiles (tile+2, tile+3)
+      Pair pa_next;
+      geom(tile + 2 * TPP, pa_next);
+      if (pa_next.live) load_frags(pa_next, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (pb.live) {
+        mfmas(pb, f1);
+        epilogue(pa);
+      } else {
+        load_next_weights();
+        epilogue(pa);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (pb.live && !pa_next.live) {   // pb was the last pair
+        load_next_weights();
+        epilogue(pb);
+        pb.live = false;
+      }
+      pa = pa_next;
+    }
+  } else {
+    uint4 f0[TPP][kSteps];
+    for (int tile = tile_lo; tile < tile_hi; tile += TPP) {
+      Pair pa;
+      geom(tile, pa);
+      load_frags(pa, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(pa, f0);
+      epilogue(pa);
+      if (tile + TPP >= tile_hi) load_next_weights();
+    }
+  }
+}
+
+template <int C, int NB, int MODE, int NT, int TPP>
+__global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   using G = Geo<C, NB>;
   extern __shared__ __attribute__((aligned(256))) uint8_t lds_raw[];
   uint4* X = reinterpret_cast<uint4*>(lds_raw);    // block input / residual stream
@@ -74,16 +224,29 @@ __global__ __launch_bounds__(256) void c4_conv_tower_kernel(TowerParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int li = lane & 15;   // cell within the tile / MFMA column
-  const int lg = lane >> 4;   // MFMA k-group (0..3)
   const uint32_t board0 = blockIdx.x * NB;
 
+  // A fragments (weights) of the current layer, in registers; conv0 uses the first 3 k-steps
+  constexpr int kWSteps = 9 * G::KC;
+  bf16x8 wf[kWSteps][G::MT];
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int m = 0; m < G::MT; m++) wf[k][m] = p.w0[(k * G::MT + m) * 64 + lane];
+  auto load_layer_weights = [&](int layer) __attribute__((always_inline)) {   // layer >= 1: [t][m][kc][lane]
+    const bf16x8* wl = p.w + (size_t)(layer - 1) * 9 * G::MT * G::KC * 64;
+#pragma unroll
+    for (int k = 0; k < kWSteps; k++)
+#pragma unroll
+      for (int m = 0; m < G::MT; m++) wf[k][m] = wl[(((k / G::KC) * G::MT + m) * G::KC + (k % G::KC)) * 64 + lane];
+  };
+
   // ---- zero both images (halo cells stay zero for the whole kernel) ----
-  for (int i = tid; i < 2 * G::kBufSlots; i += 256) X[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < 2 * G::kBufSlots; i += NT) X[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
 
   // ---- stage the input planes: channel group 0 of T holds {plane0, plane1, 0 x6} per cell ----
-  for (int i = tid; i < NB * 42; i += 256) {
+  for (int i = tid; i < NB * 42; i += NT) {
     const int b = i / 42, cell = i - b * 42;
     const uint32_t g = board0 + b;
     if (g < p.n_boards) {
@@ -94,117 +257,29 @@ __global__ __launch_bounds__(256) void c4_conv_tower_kernel(TowerParams p) {
   }
   __syncthreads();
 
-  const int n_layers = 1 + 2 * (int)p.n_blocks;
-  // tiles of this wave: contiguous range, processed two at a time
-  constexpr int kTilesPerWave = (G::kTiles + 3) / 4;
+  // tiles of this wave: a contiguous range
+  constexpr int kWaves = NT / 64;
+  constexpr int kTilesPerWave = (G::kTiles + kWaves - 1) / kWaves;
   const int tile_lo = wave * kTilesPerWave;
   const int tile_hi = (tile_lo + kTilesPerWave < G::kTiles) ? tile_lo + kTilesPerWave : G::kTiles;
+  const int n_layers = 2 * (int)p.n_blocks;
 
-  for (int layer = 0; layer < n_layers; layer++) {
-    const bool is_conv0 = layer == 0;
-    const bool is_second = !is_conv0 && ((layer & 1) == 0);   // layers 2,4,..: second conv of a block
-    // source / destination images: conv0: T(input) -> X ; first conv: X -> T ; second conv: T -> X (+= residual)
-    const uint4* src = (is_conv0 || is_second) ? T : X;
-    uint4* dst = (is_conv0 || is_second) ? X : T;
-
-    // ---- this layer's weights and bias into registers ----
-    bf16x8 wf[9][G::MT][G::KC];
-    if (is_conv0) {
-#pragma unroll
-      for (int s = 0; s < 3; s++)
-#pragma unroll
-        for (int m = 0; m < G::MT; m++) wf[s][m][0] = p.w0[(s * G::MT + m) * 64 + lane];
-    } else {
-      const bf16x8* wl = p.w + (size_t)(layer - 1) * 9 * G::MT * G::KC * 64;
-#pragma unroll
-      for (int t = 0; t < 9; t++)
-#pragma unroll
-        for (int m = 0; m < G::MT; m++)
-#pragma unroll
-          for (int kc = 0; kc < G::KC; kc++) wf[t][m][kc] = wl[((t * G::MT + m) * G::KC + kc) * 64 + lane];
-    }
-    f32x4 bias4[G::MT];
-#pragma unroll
-    for (int m = 0; m < G::MT; m++) {
-      const float* bp = p.bias + (size_t)layer * C + 16 * m + 4 * lg;
-      bias4[m] = f32x4{bp[0], bp[1], bp[2], bp[3]};
-    }
-
-    for (int tile = tile_lo; tile < tile_hi; tile += 2) {
-      const bool two = tile + 1 < tile_hi;
-      int bidx[2], slot[2];
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int tl = (u == 1 && !two) ? tile : tile + u;
-        bidx[u] = tl / kTilesPerBoard;
-        slot[u] = 9 + 16 * (tl - bidx[u] * kTilesPerBoard) + li;   // cell_slot of the tile's first cell is 9 + 16 j
-      }
-      f32x4 acc[2][G::MT];
-#pragma unroll
-      for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int m = 0; m < G::MT; m++) acc[u][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-      if (is_conv0) {
-        // k-step s, k-group lg <-> tap 4 s + lg (taps >= 9 have zero weights); 8 "channels" per tap, 2 real
-#pragma unroll
-        for (int s = 0; s < 3; s++) {
-          int tap = 4 * s + lg;
-          tap = tap < 9 ? tap : 4;
-          const int d = 8 * (tap / 3 - 1) + (tap % 3 - 1);
-#pragma unroll
-          for (int u = 0; u < 2; u++) {
-            const uint4 raw = src[bidx[u] * kPCS + slot[u] + d];
-            const bf16x8 bf = __builtin_bit_cast(bf16x8, raw);
-#pragma unroll
-            for (int m = 0; m < G::MT; m++)
-              acc[u][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][m][0], bf, acc[u][m], 0, 0, 0);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 9; t++) {
-          const int d = 8 * (t / 3 - 1) + (t % 3 - 1);
-#pragma unroll
-          for (int kc = 0; kc < G::KC; kc++) {
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-              const uint4 raw = src[((4 * kc + lg) * NB + bidx[u]) * kPCS + slot[u] + d];
-              const bf16x8 bf = __builtin_bit_cast(bf16x8, raw);
-#pragma unroll
-              for (int m = 0; m < G::MT; m++)
-                acc[u][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][m][kc], bf, acc[u][m], 0, 0, 0);
-            }
-          }
-        }
-      }
-
-      // ---- epilogue: lane holds output channels 16 m + 4 lg + {0..3} of cell `slot` ----
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        if (u == 1 && !two) break;
-        const bool valid = ((slot[u] - 1) & 7) != 0;   // padded column 0 is halo
-        if (!valid) continue;
-#pragma unroll
-        for (int m = 0; m < G::MT; m++) {
-          f32x4 v = acc[u][m] + bias4[m];
-          // 8-byte half of the 16-byte slot of channel group 2 m + lg/2
-          uint2* dp = reinterpret_cast<uint2*>(&dst[((2 * m + (lg >> 1)) * NB + bidx[u]) * kPCS + slot[u]]) + (lg & 1);
-          if (is_second) {
-            const bf16x4 old = __builtin_bit_cast(bf16x4, *dp);
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = (float)old[r] + (v[r] > 0.f ? v[r] : 0.f);
-          }
-          const bf16x4 o = __builtin_convertvector(v, bf16x4);
-          *dp = __builtin_bit_cast(uint2, o);
-        }
-      }
-    }
+  // conv0: input image (T) -> X
+  tower_layer<C, NB, true, MODE, TPP>(T, X, wf, p.bias, false, tile_lo, tile_hi, lane, [&]() __attribute__((always_inline)) {
+    if (n_layers >= 1) load_layer_weights(1);
+  });
+  __syncthreads();
+  for (int layer = 1; layer <= n_layers; layer++) {
+    const bool is_second = (layer & 1) == 0;         // second conv of a block: T -> X, += residual
+    tower_layer<C, NB, false, MODE, TPP>(is_second ? T : X, is_second ? X : T, wf, p.bias + (size_t)layer * C, is_second, tile_lo,
+                              tile_hi, lane, [&]() __attribute__((always_inline)) {
+                                if (layer < n_layers) load_layer_weights(layer + 1);
+                              });
     __syncthreads();
   }
 
   // ---- X -> out[g][cell][C] ----
-  for (int i = tid; i < NB * 42 * G::KG; i += 256) {
+  for (int i = tid; i < NB * 42 * G::KG; i += NT) {
     const int kg = i % G::KG;
     const int bc = i / G::KG;
     const int b = bc / 42, cell = bc - b * 42;
@@ -236,16 +311,22 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   if (channels == 32) {
     constexpr int NB = 16;
     constexpr int kLds = Geo<32, NB>::kLdsBytes;
-    auto k = c4_conv_tower_kernel<32, NB>;
+    static const int mode = getenv("C4_TOWER_MODE") ? atoi(getenv("C4_TOWER_MODE")) : 2;
+    auto k = mode == 1 ? c4_conv_tower_kernel<32, NB, 1, 256, 2>
+             : mode == 0 ? c4_conv_tower_kernel<32, NB, 0, 256, 2>
+             : mode == 3 ? c4_conv_tower_kernel<32, NB, 0, 768, 1>
+             : mode == 4 ? c4_conv_tower_kernel<32, NB, 0, 512, 1>
+                         : c4_conv_tower_kernel<32, NB, 0, 512, 2>;
+    const int nt = mode == 3 ? 768 : ((mode == 2 || mode == 4) ? 512 : 256);
     e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (e == hipSuccess) {
-      k<<<dim3((n_boards + NB - 1) / NB), dim3(256), kLds, (hipStream_t)stream>>>(p);
+      k<<<dim3((n_boards + NB - 1) / NB), dim3(nt), kLds, (hipStream_t)stream>>>(p);
       e = hipGetLastError();
     }
   } else if (channels == 64) {
     constexpr int NB = 8;
     constexpr int kLds = Geo<64, NB>::kLdsBytes;
-    auto k = c4_conv_tower_kernel<64, NB>;
+    auto k = c4_conv_tower_kernel<64, NB, 0, 256, 1>;
     e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (e == hipSuccess) {
       k<<<dim3((n_boards + NB - 1) / NB), dim3(256), kLds, (hipStream_t)stream>>>(p);
@@ -277,26 +358,32 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void c4_head_out_kernel(const uint4* __restrict__ hp, const uint4* __restrict__ hv,
                                                           const uint4* __restrict__ wp, const uint4* __restrict__ wv,
                                                           const float* __restrict__ bp, const float* __restrict__ bv,
-                                                          uint32_t n_boards, uint32_t f8, float* __restrict__ logprobs,
-                                                          float* __restrict__ q) {
+                                                          uint32_t n_boards, uint32_t f8, uint32_t sp8, uint32_t sv8,
+                                                          float* __restrict__ logprobs, float* __restrict__ q) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (g >= n_boards) return;
   float accp[7] = {0, 0, 0, 0, 0, 0, 0}, accv[2] = {0, 0};
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   for (uint32_t i = lane; i < f8; i += 64) {
-    const bf16x8 xp = __builtin_bit_cast(bf16x8, hp[(size_t)g * f8 + i]);
-    const bf16x8 xv = __builtin_bit_cast(bf16x8, hv[(size_t)g * f8 + i]);
+    const uint4 xp = hp[(size_t)g * sp8 + i];
+    const uint4 xv = hv[(size_t)g * sv8 + i];
+    const uint32_t xpw[4] = {xp.x, xp.y, xp.z, xp.w}, xvw[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
     for (int o = 0; o < 7; o++) {
-      const bf16x8 w = __builtin_bit_cast(bf16x8, wp[(size_t)o * f8 + i]);
+      const uint4 w = wp[(size_t)o * f8 + i];
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-      for (int j = 0; j < 8; j++) accp[o] += (float)xp[j] * (float)w[j];
+      for (int j = 0; j < 4; j++)   // v_dot2c_f32_bf16: two bf16 products accumulated in f32
+        accp[o] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, xpw[j]), __builtin_bit_cast(bf16x2, ww[j]), accp[o], false);
     }
 #pragma unroll
     for (int o = 0; o < 2; o++) {
-      const bf16x8 w = __builtin_bit_cast(bf16x8, wv[(size_t)o * f8 + i]);
+      const uint4 w = wv[(size_t)o * f8 + i];
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-      for (int j = 0; j < 8; j++) accv[o] += (float)xv[j] * (float)w[j];
+      for (int j = 0; j < 4; j++)
+        accv[o] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, xvw[j]), __builtin_bit_cast(bf16x2, ww[j]), accv[o], false);
     }
   }
 #pragma unroll
@@ -322,13 +409,14 @@ __global__ __launch_bounds__(256) void c4_head_out_kernel(const uint4* __restric
 
 extern "C" int c4_head_out_bf16(const void* hidden_policy_dev, const void* hidden_value_dev, const void* w_policy_dev,
                                 const void* w_value_dev, const float* b_policy_dev, const float* b_value_dev,
-                                uint32_t n_boards, uint32_t features, float* logprobs_dev, float* q_dev, void* stream) {
+                                uint32_t n_boards, uint32_t features, uint32_t policy_row_stride, uint32_t value_row_stride,
+                                float* logprobs_dev, float* q_dev, void* stream) {
   if (!hidden_policy_dev || !hidden_value_dev || !w_policy_dev || !w_value_dev || !b_policy_dev || !b_value_dev || !logprobs_dev || !q_dev)
     return C4_ERR_BAD_ARG;
-  if (features % 8 != 0) return C4_ERR_BAD_ARG;
+  if (features % 8 != 0 || policy_row_stride % 8 != 0 || value_row_stride % 8 != 0) return C4_ERR_BAD_ARG;
   if (n_boards == 0) return C4_OK;
   c4_head_out_kernel<<<dim3((n_boards + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(
       (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
-      b_policy_dev, b_value_dev, n_boards, features / 8, logprobs_dev, q_dev);
+      b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
   return hipGetLastError() == hipSuccess ? C4_OK : C4_ERR_HIP;
 }

@@ -177,6 +177,10 @@ class InferenceNet:
         self.conv_w = [w.to(self.device, dtype).contiguous(memory_format=torch.channels_last) for w in self.conv_w]
         self.conv_b = mv(self.conv_b)
         self.pol_w, self.pol_b, self.val_w, self.val_b = mv(self.pol_w), mv(self.pol_b), mv(self.val_w), mv(self.val_b)
+        self.merged_w1 = self.merged_b1 = None
+        if len(self.pol_w) > 1 and len(self.val_w) > 1:
+            self.merged_w1 = torch.cat([self.pol_w[0], self.val_w[0]], dim=0).contiguous()
+            self.merged_b1 = torch.cat([self.pol_b[0], self.val_b[0]], dim=0).contiguous()
 
     @torch.no_grad()
     def tower(self, planes: torch.Tensor) -> torch.Tensor:
@@ -206,11 +210,18 @@ class InferenceNet:
     def forward(self, planes: torch.Tensor, out_logprobs: Optional[torch.Tensor] = None,
                 out_q: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         x = self.tower(planes)
-        p = x
-        for w, b in zip(self.pol_w[:-1], self.pol_b[:-1]):
+        if self.merged_w1 is not None:
+            # first hidden layer of BOTH heads as one GEMM (same input, N = 2F): better tile occupancy
+            h = self._linear_relu(x, self.merged_w1, self.merged_b1)
+            f = self.merged_w1.shape[0] // 2
+            p, v = h[:, :f], h[:, f:]
+            pol_rest, val_rest = list(zip(self.pol_w[1:-1], self.pol_b[1:-1])), list(zip(self.val_w[1:-1], self.val_b[1:-1]))
+        else:
+            p = v = x
+            pol_rest, val_rest = list(zip(self.pol_w[:-1], self.pol_b[:-1])), list(zip(self.val_w[:-1], self.val_b[:-1]))
+        for w, b in pol_rest:
             p = self._linear_relu(p, w, b)
-        v = x
-        for w, b in zip(self.val_w[:-1], self.val_b[:-1]):
+        for w, b in val_rest:
             v = self._linear_relu(v, w, b)
         if self.hip_tower:
             # both output layers + log-softmax + tanh in one HIP launch, written in place
@@ -220,11 +231,11 @@ class InferenceNet:
             g = x.shape[0]
             lp = out_logprobs if out_logprobs is not None else torch.empty((g, 7), dtype=torch.float32, device=self.device)
             q = out_q if out_q is not None else torch.empty((g, 2), dtype=torch.float32, device=self.device)
-            p, v = p.contiguous(), v.contiguous()
+            assert p.stride(1) == 1 and v.stride(1) == 1
             check(self._L.c4_head_out_bf16(C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()),
                                            C.c_void_p(self.pol_w[-1].data_ptr()), C.c_void_p(self.val_w[-1].data_ptr()),
                                            C.c_void_p(self.pol_b32.data_ptr()), C.c_void_p(self.val_b32.data_ptr()),
-                                           g, p.shape[1], C.c_void_p(lp.data_ptr()), C.c_void_p(q.data_ptr()),
+                                           g, p.shape[1], p.stride(0), v.stride(0), C.c_void_p(lp.data_ptr()), C.c_void_p(q.data_ptr()),
                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             return lp, q
         p = F.linear(p, self.pol_w[-1], self.pol_b[-1]).float()

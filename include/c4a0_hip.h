@@ -193,13 +193,15 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
                        uint32_t n_boards, uint32_t channels, uint32_t n_blocks, void* out_dev, void* stream);
 
 /* Output layers of both heads in one launch (nn.py:84-85,98-99): policy Linear(F->7) + LogSoftmax
- * and value Linear(F->2) + Tanh.  hidden_*_dev bf16 [n_boards][features] (the last hidden
- * activation of each head; the same pointer twice when a head has no hidden layer), w_* bf16
+ * and value Linear(F->2) + Tanh.  hidden_*_dev bf16 [n_boards][features] with row strides
+ * *_row_stride elements (the last hidden activation of each head; they may be two column ranges
+ * of one merged tensor, or the same pointer twice when a head has no hidden layer), w_* bf16
  * [7|2][features], b_* f32; writes logprobs_dev f32 [n_boards][7] and q_dev f32 [n_boards][2]
  * (the tensors bound with c4_session_bind_io).  features % 8 == 0. */
 int c4_head_out_bf16(const void* hidden_policy_dev, const void* hidden_value_dev, const void* w_policy_dev,
                      const void* w_value_dev, const float* b_policy_dev, const float* b_value_dev,
-                     uint32_t n_boards, uint32_t features, float* logprobs_dev, float* q_dev, void* stream);
+                     uint32_t n_boards, uint32_t features, uint32_t policy_row_stride, uint32_t value_row_stride,
+                     float* logprobs_dev, float* q_dev, void* stream);
 
 #ifdef __cplusplus
 }
