@@ -101,7 +101,9 @@ def main():
     ap.add_argument("--preroll", type=int, default=-1, help="untimed steps to reach steady state (-1 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
-    ap.add_argument("--eager", action="store_true", help="do not capture the evaluator in a HIP graph")
+    ap.add_argument("--eager", action="store_true", help="no HIP graph: launch every kernel from the host")
+    ap.add_argument("--steps-per-graph", type=int, default=8)
+    ap.add_argument("--instrumented-steps", type=int, default=300, help="event-bracketed launches for the roofline object")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,7 +123,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from c4a0_amd.nn import ConnectFourNet, GraphedEvaluator, InferenceNet, ModelConfig, flops_per_leaf
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig, flops_per_leaf
     from c4a0_amd.session import DeviceSession
 
     G, n_iter = args.games_per_gpu, args.n_mcts
@@ -131,34 +133,36 @@ def main():
 
     sess = DeviceSession(G, n_iter, 6.6, 0.01, device=device, planes_dtype=torch.bfloat16)
     preroll = args.preroll if args.preroll >= 0 else int(2.0 * 15.0 * n_iter)  # ~2 game lengths of sims
-    total_steps = preroll + args.warmup + args.steps
+    total_steps = preroll + args.warmup + args.steps + args.instrumented_steps + 64
     sims_per_game_lo = 8 * n_iter  # generous lower bound on sims per game -> upper bound on games needed
     n_games = int(G * (2 + total_steps / sims_per_game_lo)) + G
     # ids sharded id % world == rank: rank r plays ids r, r+W, ...
     sess.set_games([(rank + world * i, 0, 0) for i in range(n_games)])
     sess.bind()
     sess.start()
-    evaluator = net if args.eager else GraphedEvaluator(net, sess.planes, sess.logprobs, sess.q)
+    U = 1 if args.eager else max(1, args.steps_per_graph)
+    graph = None if args.eager else sess.capture_steps(net, U)
+    if args.eager:
+        sess.set_timing(False)
 
-    def run_steps(k, events=None):
-        for i in range(k):
-            sess.evaluate(evaluator)
-            if events is not None:
-                events[i][0].record()
-                sess.step()
-                events[i][1].record()
-            else:
-                sess.step()
+    def run_steps(k):
+        """k lock-step rounds: HIP-graph replays of U rounds each, remainder launched eagerly."""
+        if graph is not None:
+            for _ in range(k // U):
+                graph.replay()
+            k = k % U
+        for _ in range(k):
+            sess.evaluate(net)
+            sess.step()
 
     run_steps(preroll)
     run_steps(args.warmup)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     c0 = sess.counters()  # synchronises the stream
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(args.steps, ev)
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -166,11 +170,29 @@ def main():
     c1 = sess.counters()
     if c1["error"]:
         sys.exit(f"device error {c1['error']} in slot {c1['error_slot']}")
-    if c1["games_started"] >= n_games:
-        sys.exit("bench ran out of queued games; raise n_games")
     d = {k: c1[k] - c0[k] for k in c1 if k not in ("error", "error_slot")}
     elapsed = t1 - t0
-    step_kernel_ms = sum(a.elapsed_time(b) for a, b in ev)
+
+    # ---- instrumented segment right after the timed steps (same steady state): the step kernel
+    # bracketed by HIP events on its stream, and timed on the device clock inside the kernel.
+    # (Inside the graph-replayed region nothing can be bracketed per launch.)
+    n_inst = max(1, min(args.steps, args.instrumented_steps))
+    sess.set_timing(True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_inst)]
+    ci0 = sess.counters()
+    for a_ev, b_ev in ev:
+        sess.evaluate(net)
+        a_ev.record()
+        sess.step()
+        b_ev.record()
+    torch.cuda.synchronize()
+    ci1 = sess.counters()
+    if ci1["error"]:
+        sys.exit(f"device error {ci1['error']} in slot {ci1['error_slot']}")
+    if ci1["games_started"] >= n_games:
+        sys.exit("bench ran out of queued games; raise n_games")
+    di = {k: ci1[k] - ci0[k] for k in ci1 if k not in ("error", "error_slot")}
+    step_kernel_ms = sum(a_ev.elapsed_time(b_ev) for a_ev, b_ev in ev)
 
     games, sims, elapsed_max = float(d["games_done"]), float(d["sims"]), elapsed
     if dist is not None:
@@ -184,13 +206,13 @@ def main():
         skipped = float(d["ref_skipped_sims"])
 
     if rank == 0:
-        ab = algorithmic_bytes(d, 2)
-        avg_kernel_s = step_kernel_ms / 1e3 / max(1, args.steps)          # HIP events around each launch
-        achieved = ab["total"] / max(1, args.steps) / avg_kernel_s / 1e9
+        ab = algorithmic_bytes(di, 2)
+        avg_kernel_s = step_kernel_ms / 1e3 / n_inst                       # HIP events around each launch
+        achieved = ab["total"] / n_inst / avg_kernel_s / 1e9
         # the same launches on the device clock (first wavefront start -> last wavefront end,
         # s_memrealtime stamps taken inside the kernel): what rocprofv3's kernel duration measures
-        dev_s = d["step_kernel_ns"] / 1e9 / max(1, d["step_launches"])
-        achieved_dev = ab["total"] / max(1, args.steps) / max(dev_s, 1e-12) / 1e9
+        dev_s = di["step_kernel_ns"] / 1e9 / max(1, di["step_launches"])
+        achieved_dev = ab["total"] / n_inst / max(dev_s, 1e-12) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "step_kernel_traffic.json")
         if os.path.exists(tpath):
@@ -199,7 +221,7 @@ def main():
             except Exception:
                 traffic = None
         fl = flops_per_leaf(cfg)
-        nn_s = max(1e-9, elapsed - step_kernel_ms / 1e3)
+        nn_s = max(1e-9, elapsed - dev_s * args.steps)
         out = {
             "metric": "self-play games/sec (and MCTS sims/sec) at n_mcts=100",
             "value": games / elapsed_max,
@@ -216,7 +238,7 @@ def main():
             "config": {"workload": f"BASELINE config 2 per GPU: {G} concurrent games, n_mcts_iterations={n_iter}, "
                                    f"{cfg.n_residual_blocks}-block/{cfg.conv_filter_size}-ch ResNet bf16, c_exploration=6.6, c_ply_penalty=0.01",
                        "games_per_gpu": G, "n_mcts_iterations": n_iter, "parallelism": f"games sharded id%{world}",
-                       "evaluator": "eager" if args.eager else "hip-graph", "preroll_steps": preroll,
+                       "evaluator": "eager" if args.eager else f"hip-graph x{U} steps (evaluator + step kernel)", "preroll_steps": preroll,
                        "tree_dtype": "u64 bitboards + f32 UCT"},
             "sims_per_s": sims / elapsed_max,
             "ref_equivalent_sims_per_s": (sims + skipped) / elapsed_max,
@@ -228,14 +250,15 @@ def main():
                          "avg_launch_us": avg_kernel_s * 1e6,
                          "device_clock": {"avg_kernel_us": dev_s * 1e6, "achieved": achieved_dev, "frac": achieved_dev / HBM_PEAK_GBPS,
                                           "note": "in-kernel s_memrealtime stamps; the HIP-event bracket adds the dispatch and completion latency of one launch"},
-                         "algorithmic_bytes_per_launch": ab["total"] / max(1, args.steps),
-                         "bytes_per_sim": {k: v / max(1, d["sims"]) for k, v in ab.items()},
-                         "S_per_sim": d["select_levels"] / max(1, d["sims"]), "K_per_sim": d["backup_nodes"] / max(1, d["sims"]),
-                         "E_per_sim": d["expansions"] / max(1, d["sims"])},
+                         "launches_measured": n_inst,
+                         "algorithmic_bytes_per_launch": ab["total"] / n_inst,
+                         "bytes_per_sim": {k: v / max(1, di["sims"]) for k, v in ab.items()},
+                         "S_per_sim": di["select_levels"] / max(1, di["sims"]), "K_per_sim": di["backup_nodes"] / max(1, di["sims"]),
+                         "E_per_sim": di["expansions"] / max(1, di["sims"])},
             "nn": {"bound": "mfma", "flops_per_leaf": fl, "achieved": fl * G * args.steps / nn_s / 1e12,
                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": fl * G * args.steps / nn_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                   "note": "wall time minus step-kernel time; includes launch gaps"},
+                   "note": "wall time of the timed steps minus step-kernel device time; includes launch gaps"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

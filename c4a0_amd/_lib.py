@@ -62,6 +62,7 @@ SIGNATURES = {
     "c4_session_bind_io": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "c4_session_start": (C.c_int, [_vp]),
     "c4_session_step": (C.c_int, [_vp]),
+    "c4_session_set_timing": (C.c_int, [_vp, C.c_int]),
     "c4_session_counters": (C.c_int, [_vp, _P(Counters)]),
     "c4_session_poll": (C.c_int, [_vp, _P(C.c_uint64), _P(C.c_uint32)]),
     "c4_session_sample_counts": (C.c_int, [_vp, _P(C.c_uint32), C.c_uint64]),

@@ -115,7 +115,9 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
             steps = sess.run(ev, poll_every=1)
         else:
             ev = evaluator
-            steps = sess.run(ev)
+            # a c4a0_amd.nn.InferenceNet is pure device code: replay it and the step kernel from a HIP graph
+            spg = 8 if getattr(evaluator, "graph_safe", False) else 0
+            steps = sess.run(ev, steps_per_graph=spg)
         counts = sess.sample_counts()
         recs = sess.drain_samples()
         if stats is not None:

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
 #ifdef C4_PHASE_STAMPS
   if (lane == 0) for (int i = 9; i < 16; i++) p.phase[(size_t)blockIdx.x * 16 + i] = 0;
 #endif
-  if (blockIdx.x == 0 && p.seq > 0) {
+  if (blockIdx.x == 0 && p.seq > 1) {
     // duration of the PREVIOUS launch = last wavefront end - first wavefront start (its stamps are
     // complete: kernel boundary); one writer, no atomics
     const unsigned long long* prev = p.stamps + (size_t)((p.seq - 1) & 1) * p.n_waves * 2;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     if (add) atomicAdd(&p.wave_ctr[(size_t)blockIdx.x * CTR_N + sub], add);
   }
   C4_STAMP(8, 0);
-  if (lane == 0) {
+  if (lane == 0 && p.seq) {
     unsigned long long* my = p.stamps + ((size_t)(p.seq & 1) * p.n_waves + blockIdx.x) * 2;
     my[0] = t_start;
     my[1] = __builtin_amdgcn_s_memrealtime();
@@ -612,6 +612,7 @@ struct c4_session {
   hipStream_t stream = nullptr;
   uint32_t n_waves = 0;
   uint32_t seq = 0;
+  bool timing = true;
   bool bound = false, have_games = false;
   uint64_t n_games = 0;
   c4_game_metadata* reqs_dev = nullptr;
@@ -767,12 +768,25 @@ int c4_session_start(c4_session* s) {
 int c4_session_step(c4_session* s) {
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
   if (!s->bound || !s->have_games) return fail(C4_ERR_NOT_BOUND, "bind_io and set_games must precede step");
-  s->p.seq = s->seq++;
+  // launch sequence number for the device-clock stamps; frozen at 0 (= no per-launch timing) when
+  // timing is off, which is what a launch captured into a HIP graph needs (arguments are baked in)
+  s->p.seq = s->timing ? ++s->seq : 0;
   if (s->cfg.planes_dtype == 0)
     hipLaunchKernelGGL(c4_step_kernel<float>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
   else
     hipLaunchKernelGGL(c4_step_kernel<uint16_t>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
   HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+int c4_session_set_timing(c4_session* s, int enable) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  // fold nothing across the switch: restart the stamp buffers
+  HIP_TRY(hipMemset(s->p.stamps, 0, (size_t)s->n_waves * 4 * sizeof(unsigned long long)));
+  if (enable && !s->timing) s->seq = 0;
+  s->timing = enable != 0;
   return C4_OK;
 }
 
@@ -799,7 +813,7 @@ int c4_session_counters(c4_session* s, c4_counters* out) {
   HIP_TRY(hipMemcpy(acc, s->p.clock_acc, sizeof acc, hipMemcpyDeviceToHost));
   if (s->seq > 0) {
     std::vector<unsigned long long> st((size_t)s->n_waves * 2);
-    HIP_TRY(hipMemcpy(st.data(), s->p.stamps + (size_t)((s->seq - 1) & 1) * s->n_waves * 2, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st.data(), s->p.stamps + (size_t)(s->seq & 1) * s->n_waves * 2, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long lo = ~0ull, hi = 0ull;
     for (size_t w = 0; w < s->n_waves; w++) { if (st[2 * w] < lo) lo = st[2 * w]; if (st[2 * w + 1] > hi) hi = st[2 * w + 1]; }
     if (hi > lo) { acc[0] += hi - lo; acc[1] += 1; }

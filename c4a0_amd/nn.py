@@ -121,6 +121,8 @@ class InferenceNet:
     `hip_tower=True` (default on a HIP device in bf16 with 32 or 64 channels) runs the conv tower
     as the hand-written MFMA kernel `c4_conv_tower_bf16`; otherwise PyTorch-ROCm convs."""
 
+    graph_safe = True  # forward() is pure device work on caller-owned outputs: may be captured in a HIP graph
+
     def __init__(self, model: ConnectFourNet, device: torch.device, dtype: torch.dtype = torch.bfloat16,
                  hip_tower: Optional[bool] = None):
         self.device = torch.device(device)

@@ -88,6 +88,35 @@ class DeviceSession:
     def step(self):
         check(self.L.c4_session_step(self._h))
 
+    def set_timing(self, enable: bool):
+        check(self.L.c4_session_set_timing(self._h, 1 if enable else 0))
+
+    def capture_steps(self, evaluator: DeviceEvaluator, steps_per_graph: int = 8) -> "torch.cuda.CUDAGraph":
+        """Capture `steps_per_graph` x (evaluator, step kernel) into one HIP graph.
+
+        The evaluator must write into the session's bound tensors without host synchronisation
+        (c4a0_amd.nn.InferenceNet does).  Per-launch device-clock timing is switched off (its
+        sequence number would be frozen in the graph).  Replay with `graph.replay()`."""
+        self.set_timing(False)
+        main = torch.cuda.current_stream(self.device)
+        # warm the evaluator up outside the capture (library handles, autotuned kernels)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.bind(side)
+            for _ in range(2):
+                self.evaluate(evaluator)
+        main.wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.bind(torch.cuda.current_stream(self.device))
+            for _ in range(steps_per_graph):
+                self.evaluate(evaluator)
+                self.step()
+        self.bind(main)
+        return graph
+
     # ---------------------------------------------------------------- results
     def counters(self) -> dict:
         c = Counters()
@@ -144,6 +173,9 @@ class DeviceSession:
 
     # ---------------------------------------------------------------- the loop
     def evaluate(self, evaluator: DeviceEvaluator):
+        if getattr(evaluator, "graph_safe", False):   # writes the bound tensors in place
+            evaluator(self.planes, out_logprobs=self.logprobs, out_q=self.q)
+            return
         lp, q = evaluator(self.planes)
         if lp.data_ptr() != self.logprobs.data_ptr():
             self.logprobs.copy_(lp.reshape(self.n_slots, 7))
@@ -151,18 +183,28 @@ class DeviceSession:
             self.q.copy_(q.reshape(self.n_slots, 2))
 
     def run(self, evaluator: DeviceEvaluator, max_steps: Optional[int] = None, poll_every: int = 16,
-            on_step: Optional[Callable[[int], None]] = None) -> int:
-        """Play all games set by set_games() to completion.  Returns the number of steps."""
+            on_step: Optional[Callable[[int], None]] = None, steps_per_graph: int = 0) -> int:
+        """Play all games set by set_games() to completion.  Returns the number of steps.
+
+        steps_per_graph > 0 replays a HIP graph of that many (evaluator, step) rounds per host
+        iteration -- for evaluators that are pure device code (no host callbacks)."""
         self.bind()
         self.start()
         steps = 0
+        graph = self.capture_steps(evaluator, steps_per_graph) if steps_per_graph > 0 else None
         while True:
-            self.evaluate(evaluator)
-            if on_step is not None:
-                on_step(steps)
-            self.step()
-            steps += 1
-            if steps % poll_every == 0:
+            if graph is not None:
+                graph.replay()
+                steps += steps_per_graph
+                check_now = True
+            else:
+                self.evaluate(evaluator)
+                if on_step is not None:
+                    on_step(steps)
+                self.step()
+                steps += 1
+                check_now = steps % poll_every == 0
+            if check_now:
                 done, err = self.poll()
                 if err:
                     self.raise_if_device_error()
@@ -170,6 +212,9 @@ class DeviceSession:
                     break
             if max_steps is not None and steps >= max_steps:
                 break
+        if graph is not None:
+            torch.cuda.synchronize(self.device)
+            self.set_timing(True)
         c = self.counters()
         if c["error"]:
             raise C4Error(c["error"], f"raised on device by slot {c['error_slot']}")

@@ -129,6 +129,12 @@ int c4_session_start(c4_session* s);
  * finished games, select the next leaves and write them to planes_dev.  Asynchronous. */
 int c4_session_step(c4_session* s);
 
+/* Per-launch device-clock timing of the step kernel (c4_counters.step_kernel_ns) needs a launch
+ * sequence number in the kernel arguments, which a HIP-graph capture would freeze: switch it
+ * off before capturing c4_session_step into a graph, on again for eager launches.  On by
+ * default.  Synchronises. */
+int c4_session_set_timing(c4_session* s, int enable);
+
 /* Synchronises the stream and sums the per-wavefront counters. */
 int c4_session_counters(c4_session* s, c4_counters* out);
 /* Non-blocking completion probe: enqueues a copy of (games_done, error) to pinned host
