@@ -1,0 +1,153 @@
+"""GPU tests of the drop-in entry point `play_games` (reference rust/src/pybridge.rs:20-53), written
+after the reference's own boundary tests (tests/c4a0_tests/pybridge_test.py, tournament_test.py)
+plus parity of the results against the CPU oracle."""
+import pickle
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _uniform_eval(_model_id, pos):                      # pybridge_test.py:7-11
+    b = pos.shape[0]
+    return np.zeros((b, 7), dtype=np.float32), np.zeros((b,), dtype=np.float32), np.zeros((b,), dtype=np.float32)
+
+
+def _as_oracle_dict(result):
+    return {r.metadata.game_id: [(s.mask, s.value, s.policy.tobytes(), s.q_penalty.tobytes(), s.q_no_penalty.tobytes())
+                                 for s in r.samples] for r in result.results}
+
+
+def test_split_train_test_is_deterministic_and_non_mutating():
+    """pybridge_test.py:22-39, verbatim scenario through the GPU-backed play_games."""
+    import c4a0_amd as c4a0_rust
+
+    games = c4a0_rust.play_games([c4a0_rust.GameMetadata(i, 0, 0) for i in range(4)], 8, 2, 1.4, 0.01, _uniform_eval)
+    ids = [r.metadata.game_id for r in games.results]
+    first_train, first_test = games.split_train_test(0.5, 1337)
+    assert [r.metadata.game_id for r in games.results] == ids
+    second_train, second_test = games.split_train_test(0.5, 1337)
+    assert [s.pos_str() for s in first_train] == [s.pos_str() for s in second_train]
+    assert [s.pos_str() for s in first_test] == [s.pos_str() for s in second_test]
+
+
+def test_callback_mode_matches_oracle_and_honours_the_callback_contract():
+    """BASELINE config 1 shape (32 games, n_mcts_iterations = 10) through the numpy callback:
+    batches <= max_nn_batch_size, unique positions, float32 [B,2,6,7] (pybridge.rs:161-221),
+    samples identical to the oracle driven by the same callback."""
+    import c4a0_amd
+    from oracle import c4oracle as O
+    from tests.helpers import hash_eval_np, oracle_samples_by_game
+
+    seen = []
+
+    def cb(model_id, x):
+        assert x.dtype == np.float32 and x.shape[1:] == (2, 6, 7) and x.flags["C_CONTIGUOUS"]
+        assert len({x[i].tobytes() for i in range(x.shape[0])}) == x.shape[0]
+        seen.append(x.shape[0])
+        return hash_eval_np(model_id, x)
+
+    reqs = [c4a0_amd.GameMetadata(i, 0, 0) for i in range(32)]
+    stats = {}
+    got = c4a0_amd.play_games(reqs, 5, 10, 6.6, 0.01, cb, stats=stats)
+    assert max(seen) <= 5 and seen[0] == 1                  # all games start on the same position
+    want, ost = O.self_play([(i, 0, 0) for i in range(32)], 5, 10, 6.6, 0.01, "hash")
+    assert _as_oracle_dict(got) == oracle_samples_by_game(want)
+    assert [r.metadata.game_id for r in got.results] == list(range(32))
+    assert stats["games_done"] == 32 and stats["samples"] == ost["n_samples"]
+    # the result container round-trips through CBOR and pickle (pybridge.rs:73-92)
+    assert type(got).from_cbor(got.to_cbor()) == got and pickle.loads(pickle.dumps(got)) == got
+    # every game ends in exactly one terminal sample whose score is defined (types.rs:77-99)
+    assert all(0.0 <= r.player0_score() <= 1.0 for r in got.results)
+
+
+def test_callback_errors_surface_as_exceptions():
+    import c4a0_amd
+
+    reqs = [c4a0_amd.GameMetadata(i, 0, 0) for i in range(3)]
+    with pytest.raises(TypeError):      # wrong dtype (reference: "Failed to extract result", pybridge.rs:184)
+        c4a0_amd.play_games(reqs, 8, 2, 1.4, 0.01, lambda m, x: (np.zeros((x.shape[0], 7)), np.zeros(x.shape[0]), np.zeros(x.shape[0])))
+    with pytest.raises(ZeroDivisionError):   # callback raised (reference: panic, pybridge.rs:182-183)
+        c4a0_amd.play_games(reqs, 8, 2, 1.4, 0.01, lambda m, x: 1 / 0)
+    with pytest.raises(TypeError):
+        c4a0_amd.play_games(reqs, 8, 2, 1.4, 0.01)
+    assert c4a0_amd.play_games([], 8, 2, 1.4, 0.01, _uniform_eval).results == []
+
+
+def test_tournament_style_multi_model_games():
+    """tournament_test.py:27-51: players with different ids; the callback is dispatched on the
+    model to play at the leaf (mcts.rs:70-76); ids are preserved and scores are in [0, 1].
+    Per-game results equal the oracle's (which restates the reference's majority-model batching)."""
+    import itertools
+
+    import c4a0_amd
+    from oracle import c4oracle as O
+    from tests.helpers import hash_eval_np, oracle_samples_by_game
+
+    def player(model_id, x):
+        lp, qp, qn = hash_eval_np(model_id, x)
+        return np.ascontiguousarray(np.roll(lp, int(model_id), axis=1)), qp, qn   # each "model" prefers other columns
+
+    calls = []
+
+    def cb(model_id, x):
+        calls.append(model_id)
+        return player(model_id, x)
+
+    pairings = list(itertools.permutations([0, 1, 2], 2))
+    reqs = [c4a0_amd.GameMetadata(i, p0, p1) for i, (p0, p1) in enumerate(pairings)]
+    got = c4a0_amd.play_games(reqs, 4, 6, 1.4, 0.01, cb)
+    assert set(calls) == {0, 1, 2}
+    assert [(r.metadata.game_id, r.metadata.player0_id, r.metadata.player1_id) for r in got.results] == \
+           [(i, p0, p1) for i, (p0, p1) in enumerate(pairings)]
+    assert all(0.0 <= r.player0_score() <= 1.0 for r in got.results)
+    want, _ = O.self_play([(i, p0, p1) for i, (p0, p1) in enumerate(pairings)], 4, 6, 1.4, 0.01, player)
+    assert _as_oracle_dict(got) == oracle_samples_by_game(want)
+
+
+def test_device_mode_with_real_network_and_t3_replay_parity():
+    """Device mode (leaves never leave HBM) with the bf16 ResNet, HIP-graph replayed.  T3 parity
+    (SURVEY 8c): the run logs every (leaf position -> evaluator output) pair it consumed; the
+    oracle replays the games with a lookup evaluator and must emit identical samples."""
+    import c4a0_amd
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+    from c4a0_amd.session import DeviceSession
+    from oracle import c4oracle as O
+    from tests.helpers import oracle_samples_by_game, planes_to_pos_np, samples_by_game
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1337)
+    net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 2, 2)), dev, dtype=torch.bfloat16)
+    reqs = [(i, 0, 0) for i in range(24)]
+    s = DeviceSession(16, 12, 6.6, 0.01, device=dev, planes_dtype=torch.bfloat16)
+    s.set_games(reqs)
+    table = {}
+
+    def log(_step):
+        # at this point planes hold the leaves and logprobs/q the evaluator's answers for them
+        _m, _v, status = s.leaves()
+        mask, value = planes_to_pos_np(s.planes.float().cpu().numpy())
+        lp, q = s.logprobs.cpu().numpy(), s.q.cpu().numpy()
+        for g in np.nonzero(status == 1)[0]:
+            key = (int(mask[g]), int(value[g]))
+            val = (lp[g].tobytes(), q[g].tobytes())
+            assert table.setdefault(key, val) == val, "evaluator must be a function of the position"
+    s.run(net, on_step=log)
+    got = samples_by_game(s.drain_samples())
+    s.close()
+
+    def lookup(_model_id, x):
+        mask, value = planes_to_pos_np(x)
+        lp = np.stack([np.frombuffer(table[(int(m), int(v))][0], dtype=np.float32) for m, v in zip(mask, value)])
+        q = np.stack([np.frombuffer(table[(int(m), int(v))][1], dtype=np.float32) for m, v in zip(mask, value)])
+        return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
+
+    want, _ = O.self_play(reqs, 64, 12, 6.6, 0.01, lookup)
+    assert got == oracle_samples_by_game(want)
+
+    # the same run through play_games(evaluator=...), HIP-graph replayed: identical samples again
+    res = c4a0_amd.play_games([c4a0_amd.GameMetadata(*r) for r in reqs], 64, 12, 6.6, 0.01, evaluator=net,
+                              resident_games=16, planes_dtype=torch.bfloat16)
+    assert _as_oracle_dict(res) == oracle_samples_by_game(want)
