@@ -90,6 +90,13 @@ def cpu_baseline(net, device, n_iter: int, threads: int, budget_s: float = 20.0)
 
 
 def main():
+    # Only the JSON line may reach stdout: libraries (RCCL prints a version banner) write to the
+    # process's fd 1 behind Python's back, so fd 1 is pointed at stderr for the whole run and the
+    # result goes to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3000)
@@ -118,7 +125,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("C4_BENCH_FORCE_DIST") == "1":  # the env knob exercises the RCCL path at world size 1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -194,6 +201,24 @@ def main():
     di = {k: ci1[k] - ci0[k] for k in ci1 if k not in ("error", "error_slot")}
     step_kernel_ms = sum(a_ev.elapsed_time(b_ev) for a_ev, b_ev in ev)
 
+    # ---- multi-GPU: the one collective of the path -- all-gather the finished samples (untimed
+    # end-of-job step; its time is reported beside the throughput)
+    allgather = None
+    if dist is not None:
+        try:
+            from c4a0_amd.distributed import all_gather_records
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg0 = time.perf_counter()
+            local = sess.pack_samples_device()
+            parts = all_gather_records(local)
+            torch.cuda.synchronize()
+            tg1 = time.perf_counter()
+            allgather = {"ms": (tg1 - tg0) * 1e3, "records_per_rank": [int(p_.shape[0]) for p_ in parts],
+                         "bytes_total": int(sum(p_.numel() for p_ in parts))}
+        except Exception as e:  # never lose the throughput line to the epilogue
+            allgather = {"error": repr(e)}
+
     games, sims, elapsed_max = float(d["games_done"]), float(d["sims"]), elapsed
     if dist is not None:
         t = torch.tensor([games, sims, float(d["ref_skipped_sims"])], dtype=torch.float64, device=device)
@@ -260,12 +285,14 @@ def main():
                    "frac": fl * G * args.steps / nn_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                    "note": "wall time of the timed steps minus step-kernel device time; includes launch gaps"},
         }
+        if allgather is not None:
+            out["sample_allgather"] = allgather
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(net, device, n_iter, min(usable_cores(), 64), args.cpu_baseline_seconds)
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     sess.close()
     if dist is not None:
         dist.barrier()

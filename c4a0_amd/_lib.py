@@ -60,6 +60,7 @@ SIGNATURES = {
     "c4_session_destroy": (C.c_int, [_vp]),
     "c4_session_set_games": (C.c_int, [_vp, _P(GameMetadataC), C.c_uint64, _P(C.c_uint64), _P(C.c_uint64)]),
     "c4_session_bind_io": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "c4_session_bind_leaf_models": (C.c_int, [_vp, _vp]),
     "c4_session_start": (C.c_int, [_vp]),
     "c4_session_step": (C.c_int, [_vp]),
     "c4_session_set_timing": (C.c_int, [_vp, C.c_int]),

@@ -80,6 +80,30 @@ class _CallbackEvaluator:
         return self.s.logprobs, self.s.q
 
 
+class _MultiModelEvaluator:
+    """Device-mode tournaments (reference tournament.py:112-142): the step kernel publishes, per
+    slot, the model that must evaluate its leaf (mcts.rs:70-76); every model present in the batch
+    evaluates the batch and its rows are selected on the device.  Where the reference serves
+    one model per NN tick (self_play.rs:203-215), all leaves are answered every step; a game's
+    trajectory only depends on the answers to its own leaves."""
+
+    def __init__(self, session: DeviceSession, evaluators: dict):
+        self.s, self.evs = session, evaluators
+        self.models = session.bind_leaf_models()
+
+    def __call__(self, planes: torch.Tensor):
+        present = torch.unique(self.models).tolist()
+        lp_out, q_out = self.s.logprobs, self.s.q
+        for mid in present:
+            if mid not in self.evs:
+                continue  # idle slots keep id 0 of an absent model
+            lp, q = self.evs[mid](planes)
+            sel = (self.models == mid)
+            lp_out.copy_(torch.where(sel[:, None], lp.reshape(-1, 7).float(), lp_out))
+            q_out.copy_(torch.where(sel[:, None], q.reshape(-1, 2).float(), q_out))
+        return lp_out, q_out
+
+
 def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iterations: int,
                c_exploration: float, c_ply_penalty: float, py_eval_pos_cb: Optional[Callable] = None, *,
                evaluator: Optional[DeviceEvaluator] = None, device=None, resident_games: Optional[int] = None,
@@ -98,8 +122,13 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
         raise ValueError("max_nn_batch_size must be >= 1 and n_mcts_iterations >= 0")
     if not reqs:
         return PlayGamesResult([])
-    if evaluator is not None and any(r.player0_id != r.player1_id for r in reqs):
-        raise NotImplementedError("device-evaluator mode plays single-model games; use the callback mode for tournaments")
+    multi = evaluator is not None and isinstance(evaluator, dict)
+    if evaluator is not None and not multi and any(r.player0_id != r.player1_id for r in reqs):
+        raise TypeError("games between different models need evaluator={model_id: evaluator, ...}")
+    if multi:
+        missing = {m for r in reqs for m in (r.player0_id, r.player1_id)} - set(evaluator)
+        if missing:
+            raise KeyError(f"no evaluator for model ids {sorted(missing)}")
 
     n_slots = min(len(reqs), int(resident_games) if resident_games else DEFAULT_RESIDENT_GAMES)
     if planes_dtype is None:
@@ -113,6 +142,8 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
             p1 = np.array([r.player1_id for r in reqs], dtype=np.uint64)
             ev = _CallbackEvaluator(sess, py_eval_pos_cb, max_nn_batch_size, lambda o: (p0[o], p1[o]))
             steps = sess.run(ev, poll_every=1)
+        elif multi:
+            steps = sess.run(_MultiModelEvaluator(sess, evaluator))
         else:
             ev = evaluator
             # a c4a0_amd.nn.InferenceNet is pure device code: replay it and the step kernel from a HIP graph

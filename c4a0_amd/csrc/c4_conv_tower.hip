@@ -355,53 +355,61 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// kBPW boards per wavefront share every weight chunk load (9 x 16 bytes per lane and iteration)
+template <int kBPW>
 __global__ __launch_bounds__(256) void c4_head_out_kernel(const uint4* __restrict__ hp, const uint4* __restrict__ hv,
                                                           const uint4* __restrict__ wp, const uint4* __restrict__ wv,
                                                           const float* __restrict__ bp, const float* __restrict__ bv,
                                                           uint32_t n_boards, uint32_t f8, uint32_t sp8, uint32_t sv8,
                                                           float* __restrict__ logprobs, float* __restrict__ q) {
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (g >= n_boards) return;
-  float accp[7] = {0, 0, 0, 0, 0, 0, 0}, accv[2] = {0, 0};
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t g0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kBPW;
+  if (g0 >= n_boards) return;
+  float acc[kBPW][9];
+#pragma unroll
+  for (int b = 0; b < kBPW; b++)
+#pragma unroll
+    for (int o = 0; o < 9; o++) acc[b][o] = 0.f;
   for (uint32_t i = lane; i < f8; i += 64) {
-    const uint4 xp = hp[(size_t)g * sp8 + i];
-    const uint4 xv = hv[(size_t)g * sv8 + i];
-    const uint32_t xpw[4] = {xp.x, xp.y, xp.z, xp.w}, xvw[4] = {xv.x, xv.y, xv.z, xv.w};
+    uint32_t xw[kBPW][2][4];
 #pragma unroll
-    for (int o = 0; o < 7; o++) {
-      const uint4 w = wp[(size_t)o * f8 + i];
-      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-      for (int j = 0; j < 4; j++)   // v_dot2c_f32_bf16: two bf16 products accumulated in f32
-        accp[o] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, xpw[j]), __builtin_bit_cast(bf16x2, ww[j]), accp[o], false);
+    for (int b = 0; b < kBPW; b++) {
+      const uint32_t g = (g0 + b < n_boards) ? g0 + b : g0;   // tail boards recompute board g0 (never stored)
+      const uint4 xp = hp[(size_t)g * sp8 + i], xv = hv[(size_t)g * sv8 + i];
+      xw[b][0][0] = xp.x; xw[b][0][1] = xp.y; xw[b][0][2] = xp.z; xw[b][0][3] = xp.w;
+      xw[b][1][0] = xv.x; xw[b][1][1] = xv.y; xw[b][1][2] = xv.z; xw[b][1][3] = xv.w;
     }
 #pragma unroll
-    for (int o = 0; o < 2; o++) {
-      const uint4 w = wv[(size_t)o * f8 + i];
+    for (int o = 0; o < 9; o++) {
+      const uint4 w = (o < 7) ? wp[(size_t)o * f8 + i] : wv[(size_t)(o - 7) * f8 + i];
       const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        accv[o] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, xvw[j]), __builtin_bit_cast(bf16x2, ww[j]), accv[o], false);
+      for (int b = 0; b < kBPW; b++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)   // v_dot2c_f32_bf16: two bf16 products accumulated in f32
+          acc[b][o] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, xw[b][o < 7 ? 0 : 1][j]), __builtin_bit_cast(bf16x2, ww[j]), acc[b][o], false);
     }
   }
 #pragma unroll
-  for (int o = 0; o < 7; o++) accp[o] = wave_sum(accp[o]) + bp[o];
+  for (int b = 0; b < kBPW; b++) {
+    float v[9];
 #pragma unroll
-  for (int o = 0; o < 2; o++) accv[o] = wave_sum(accv[o]) + bv[o];
-  if (lane == 0) {
-    float mx = accp[0];
+    for (int o = 0; o < 9; o++) v[o] = wave_sum(acc[b][o]) + (o < 7 ? bp[o] : bv[o - 7]);
+    const uint32_t g = g0 + b;
+    if (lane == 0 && g < n_boards) {
+      float mx = v[0];
 #pragma unroll
-    for (int o = 1; o < 7; o++) mx = fmaxf(mx, accp[o]);
-    float s = 0.f;
+      for (int o = 1; o < 7; o++) mx = fmaxf(mx, v[o]);
+      float s = 0.f;
 #pragma unroll
-    for (int o = 0; o < 7; o++) s += expf(accp[o] - mx);
-    const float lse = mx + logf(s);
+      for (int o = 0; o < 7; o++) s += expf(v[o] - mx);
+      const float lse = mx + logf(s);
 #pragma unroll
-    for (int o = 0; o < 7; o++) logprobs[(size_t)g * 7 + o] = accp[o] - lse;
-    q[(size_t)g * 2 + 0] = tanhf(accv[0]);
-    q[(size_t)g * 2 + 1] = tanhf(accv[1]);
+      for (int o = 0; o < 7; o++) logprobs[(size_t)g * 7 + o] = v[o] - lse;
+      q[(size_t)g * 2 + 0] = tanhf(v[7]);
+      q[(size_t)g * 2 + 1] = tanhf(v[8]);
+    }
   }
 }
 
@@ -415,8 +423,18 @@ extern "C" int c4_head_out_bf16(const void* hidden_policy_dev, const void* hidde
     return C4_ERR_BAD_ARG;
   if (features % 8 != 0 || policy_row_stride % 8 != 0 || value_row_stride % 8 != 0) return C4_ERR_BAD_ARG;
   if (n_boards == 0) return C4_OK;
-  c4_head_out_kernel<<<dim3((n_boards + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(
-      (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
-      b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
+  static const int bpw = getenv("C4_HEAD_BPW") ? atoi(getenv("C4_HEAD_BPW")) : 2;  // boards per wavefront (2 measured best at G = 4096)
+  if (bpw == 4)
+    c4_head_out_kernel<4><<<dim3((n_boards + 15) / 16), dim3(256), 0, (hipStream_t)stream>>>(
+        (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
+        b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
+  else if (bpw == 2)
+    c4_head_out_kernel<2><<<dim3((n_boards + 7) / 8), dim3(256), 0, (hipStream_t)stream>>>(
+        (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
+        b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
+  else
+    c4_head_out_kernel<1><<<dim3((n_boards + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(
+        (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
+        b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
   return hipGetLastError() == hipSuccess ? C4_OK : C4_ERR_HIP;
 }

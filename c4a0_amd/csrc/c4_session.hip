@@ -105,6 +105,7 @@ struct Params {
   uint32_t n_waves;
   uint32_t seq;                  // launch sequence number
   unsigned long long* phase;     // diagnostic build: [n_waves][16] phase stamps of the last launch
+  uint64_t* leaf_models;         // optional [n_slots]: model id that must evaluate each slot's leaf (mcts.rs:70-76)
   Globals* glob;
   const c4_game_metadata* reqs;
   const uint64_t* start_mask;    // may be null
@@ -143,6 +144,14 @@ C4_DEV void store_plane<float>(void* base, size_t idx, uint32_t bit) {
 template <>
 C4_DEV void store_plane<uint16_t>(void* base, size_t idx, uint32_t bit) {
   ((uint16_t*)base)[idx] = bit ? (uint16_t)0x3F80 : (uint16_t)0;  // bf16 1.0 / 0.0
+}
+
+// MctsGame::leaf_model_id_to_play (mcts.rs:70-76): player 0's model on even plies, player 1's on odd.
+C4_DEV void publish_leaf_model(const Params& p, uint32_t g, unsigned long long ordinal, uint64_t leaf_mask) {
+  if (p.leaf_models) {
+    const c4_game_metadata md = p.reqs[ordinal];
+    p.leaf_models[g] = (__popcll(leaf_mask) & 1) ? md.player1_id : md.player0_id;
+  }
 }
 
 // Put game `ordinal` on a slot: MctsGame::new_from_pos (mcts.rs:48-56).  Called by all 8 lanes.
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(64) void c4_start_kernel(Params p) {
     reset_slot(p, st, blocks, qrows, sub, g);
     m = p.start_mask ? p.start_mask[g] : 0ull;
     v = p.start_value ? p.start_value[g] : 0ull;
+    if (sub == 0) publish_leaf_model(p, g, g, m);
   } else if (sub == 0) {
     st->status = kIdle;
     st->ordinal = 0xFFFFFFFFu;
@@ -468,6 +478,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
               st->depth = d; st->n_blocks = n_blocks; st->n_moves = n_moves;
               st->path[0] = root_ref;
               st->leaf_ref = last_ref;
+              publish_leaf_model(p, g, st->ordinal, m);
             }
             C4_STAMP(6, d);
             // ---------------- leaf -> evaluator input (c4r.rs:378-392) ----------------------
@@ -750,6 +761,12 @@ int c4_session_bind_io(c4_session* s, void* planes_dev, const float* logprobs_de
   s->p.q = q_dev;
   s->stream = (hipStream_t)stream;
   s->bound = true;
+  return C4_OK;
+}
+
+int c4_session_bind_leaf_models(c4_session* s, uint64_t* leaf_models_dev) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  s->p.leaf_models = leaf_models_dev;
   return C4_OK;
 }
 

@@ -82,6 +82,12 @@ class DeviceSession:
                                         C.c_void_p(st.cuda_stream)))
         self._bound_stream = st
 
+    def bind_leaf_models(self) -> torch.Tensor:
+        """int64[n_slots] tensor that start()/step() fill with the model id to evaluate each leaf with."""
+        self.leaf_models = torch.zeros(self.n_slots, dtype=torch.int64, device=self.device)
+        check(self.L.c4_session_bind_leaf_models(self._h, C.c_void_p(self.leaf_models.data_ptr())))
+        return self.leaf_models
+
     def start(self):
         check(self.L.c4_session_start(self._h))
 

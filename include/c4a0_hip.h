@@ -119,6 +119,12 @@ int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n
 int c4_session_bind_io(c4_session* s, void* planes_dev, const float* logprobs_dev, const float* q_dev,
                        void* stream);
 
+/* Multi-model games (player0_id != player1_id: tournaments, tournament.py:112-142): when bound,
+ * every start/step also writes, for each slot, the id of the model that must evaluate its leaf
+ * (MctsGame::leaf_model_id_to_play, mcts.rs:70-76) to leaf_models_dev [n_slots] (uint64), so the
+ * caller can route rows to evaluators without leaving the device.  NULL unbinds. */
+int c4_session_bind_leaf_models(c4_session* s, uint64_t* leaf_models_dev);
+
 /* Puts the first n_slots games on the slots and writes their first leaf (the start position)
  * to planes_dev: the state self_play() is in after self_play.rs:55-58. */
 int c4_session_start(c4_session* s);

@@ -207,3 +207,30 @@ def test_gate_of_one_iteration_matches_reference_behaviour(env):
         assert got == want, gid
         n_fail += want is None
     assert 0 <= n_fail < 40
+
+
+def test_pack_samples_on_device_equals_host_drain(env):
+    """K6 (c4_session_pack_samples): finished games' records packed on the device, in request
+    order, equal the host-side drain -- including while some games are still unfinished."""
+    DeviceSession, O, dev = env
+    from c4a0_amd.session import SAMPLE_DTYPE
+    from tests.helpers import hash_eval_torch
+
+    s = DeviceSession(8, 6, 6.6, 0.01)
+    s.set_games([(i, 0, 0) for i in range(30)])
+    s.bind()
+    s.start()
+    for _ in range(90):                       # stop mid-run: some games finished, some not
+        s.evaluate(hash_eval_torch)
+        s.step()
+    for rnd in range(2):
+        host = s.drain_samples()
+        packed = s.pack_samples_device().cpu().numpy().reshape(-1).view(SAMPLE_DTYPE)
+        assert 0 < len(host) and host.tobytes() == packed.tobytes()
+        counts = s.sample_counts()
+        assert counts.sum() == len(host) and ((counts == 0).any() if rnd == 0 else (counts > 0).all())
+        for _ in range(4000):
+            s.evaluate(hash_eval_torch)
+            s.step()
+    assert (s.sample_counts() > 0).all()
+    s.close()

@@ -151,3 +151,35 @@ def test_device_mode_with_real_network_and_t3_replay_parity():
     res = c4a0_amd.play_games([c4a0_amd.GameMetadata(*r) for r in reqs], 64, 12, 6.6, 0.01, evaluator=net,
                               resident_games=16, planes_dtype=torch.bfloat16)
     assert _as_oracle_dict(res) == oracle_samples_by_game(want)
+
+
+def test_device_mode_tournament_matches_callback_mode_and_oracle():
+    """Games between different models with DEVICE evaluators (evaluator={model_id: callable}):
+    the step kernel routes every leaf to the model to play (mcts.rs:70-76).  Same samples as the
+    oracle's restatement of the reference scheduler with the numpy twins of the evaluators."""
+    import itertools
+
+    import c4a0_amd
+    from oracle import c4oracle as O
+    from tests.helpers import hash_eval_np, hash_eval_torch, oracle_samples_by_game
+
+    def dev_player(mid):
+        def f(planes):
+            lp, q = hash_eval_torch(planes)
+            return torch.roll(lp, mid, dims=1), q
+        return f
+
+    def np_player(model_id, x):
+        lp, qp, qn = hash_eval_np(model_id, x)
+        return np.ascontiguousarray(np.roll(lp, int(model_id), axis=1)), qp, qn
+
+    pairings = list(itertools.permutations([3, 5, 9], 2)) * 2
+    reqs = [c4a0_amd.GameMetadata(100 + i, p0, p1) for i, (p0, p1) in enumerate(pairings)]
+    got = c4a0_amd.play_games(reqs, 64, 8, 1.4, 0.01, evaluator={m: dev_player(m) for m in (3, 5, 9)}, resident_games=8)
+    want, _ = O.self_play([(r.game_id, r.player0_id, r.player1_id) for r in reqs], 64, 8, 1.4, 0.01, np_player)
+    assert _as_oracle_dict(got) == oracle_samples_by_game(want)
+    assert all(0.0 <= r.player0_score() <= 1.0 for r in got.results)
+    with pytest.raises(KeyError):
+        c4a0_amd.play_games(reqs, 64, 8, 1.4, 0.01, evaluator={3: dev_player(3)})
+    with pytest.raises(TypeError):
+        c4a0_amd.play_games(reqs, 64, 8, 1.4, 0.01, evaluator=dev_player(3))
