@@ -23,7 +23,6 @@
 //     two tiles are in flight per wave so consecutive MFMAs never wait on their accumulator.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include <string>
 
@@ -68,21 +67,19 @@ struct TowerParams {
 // One conv layer for this wavefront's tiles.  kConv0: the 2-channel input layer (3 k-steps whose
 // k-groups are taps); otherwise a C -> C layer (9 taps x C/32 k-steps).
 //
-// Schedule per wavefront (one wave per SIMD, so nothing else hides latency):
-//   * a "pair" = two tiles in flight = 2 x MT independent accumulators;
-//   * the B fragments of pair i+1 are requested from LDS before pair i's MFMAs;
-//   * the epilogue of pair i-1 (ReLU, residual, bf16 pack, LDS store: VALU + LDS work) is emitted
-//     in the same scheduling region as pair i's MFMAs so it fills the MFMA issue gaps;
-//   * the accumulators start at the bias;
-//   * the NEXT layer's weights are requested right after this layer's last MFMA, under the last
-//     epilogue and the barrier.
-template <int C, int NB, bool kConv0, int MODE, int TPP, typename WF, typename NextW>
+// Schedule per wavefront:
+//   * a "pair" = TPP tiles in flight = TPP x MT independent accumulators, started at the bias;
+//   * all B fragments of a pair are requested from LDS up front; counted waits let the MFMAs start
+//     as they arrive.  At C = 32 the workgroup runs 8 wavefronts (two per SIMD), so one wavefront's
+//     LDS waits and epilogue overlap the other's MFMAs (measured: better than software-pipelining
+//     a single wavefront per SIMD);
+//   * the NEXT layer's weights are requested after this layer's last epilogue, under the barrier.
+template <int C, int NB, bool kConv0, int TPP, typename WF, typename NextW>
 __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4* __restrict__ dst, WF& wf,
                                             const float* __restrict__ bias, bool is_second, int tile_lo, int tile_hi,
                                             int lane, NextW&& load_next_weights) {
   using G = Geo<C, NB>;
   constexpr int kSteps = kConv0 ? 3 : 9 * G::KC;        // MFMA k-steps (= B fragments) per tile
-  constexpr bool kDouble = (MODE == 1);                 // double-buffered fragments + overlapped epilogue
   const int li = lane & 15, lg = lane >> 4;
 
   f32x4 bias4[G::MT];
@@ -165,56 +162,19 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
     }
   };
 
-  if constexpr (kDouble) {
-    uint4 f0[TPP][kSteps], f1[TPP][kSteps];
-    Pair pa, pb;
-    geom(tile_lo, pa);
-    pb.live = false;
-    if (pa.live) load_frags(pa, f0);
-    for (int tile = tile_lo; tile < tile_hi; tile += 2 * TPP) {
-      // --- pair A = tiles (tile, tile+1); pair B of the previous round still needs its epilogue
-      Pair pb_prev = pb;
-      geom(tile + TPP, pb);
-      if (pb.live) load_frags(pb, f1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(pa, f0);
-      if (pb_prev.live) epilogue(pb_prev);
-      __builtin_amdgcn_sched_barrier(0);
-      // --- pair B = tiles (tile+2, tile+3)
-      Pair pa_next;
-      geom(tile + 2 * TPP, pa_next);
-      if (pa_next.live) load_frags(pa_next, f0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (pb.live) {
-        mfmas(pb, f1);
-        epilogue(pa);
-      } else {
-        load_next_weights();
-        epilogue(pa);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (pb.live && !pa_next.live) {   // pb was the last pair
-        load_next_weights();
-        epilogue(pb);
-        pb.live = false;
-      }
-      pa = pa_next;
-    }
-  } else {
-    uint4 f0[TPP][kSteps];
-    for (int tile = tile_lo; tile < tile_hi; tile += TPP) {
-      Pair pa;
-      geom(tile, pa);
-      load_frags(pa, f0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(pa, f0);
-      epilogue(pa);
-      if (tile + TPP >= tile_hi) load_next_weights();
-    }
+  uint4 f0[TPP][kSteps];
+  for (int tile = tile_lo; tile < tile_hi; tile += TPP) {
+    Pair pa;
+    geom(tile, pa);
+    load_frags(pa, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(pa, f0);
+    epilogue(pa);
+    if (tile + TPP >= tile_hi) load_next_weights();   // after the last epilogue: fewer live registers
   }
 }
 
-template <int C, int NB, int MODE, int NT, int TPP>
+template <int C, int NB, int NT, int TPP>
 __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   using G = Geo<C, NB>;
   extern __shared__ __attribute__((aligned(256))) uint8_t lds_raw[];
@@ -265,13 +225,13 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   const int n_layers = 2 * (int)p.n_blocks;
 
   // conv0: input image (T) -> X
-  tower_layer<C, NB, true, MODE, TPP>(T, X, wf, p.bias, false, tile_lo, tile_hi, lane, [&]() __attribute__((always_inline)) {
+  tower_layer<C, NB, true, TPP>(T, X, wf, p.bias, false, tile_lo, tile_hi, lane, [&]() __attribute__((always_inline)) {
     if (n_layers >= 1) load_layer_weights(1);
   });
   __syncthreads();
   for (int layer = 1; layer <= n_layers; layer++) {
     const bool is_second = (layer & 1) == 0;         // second conv of a block: T -> X, += residual
-    tower_layer<C, NB, false, MODE, TPP>(is_second ? T : X, is_second ? X : T, wf, p.bias + (size_t)layer * C, is_second, tile_lo,
+    tower_layer<C, NB, false, TPP>(is_second ? T : X, is_second ? X : T, wf, p.bias + (size_t)layer * C, is_second, tile_lo,
                               tile_hi, lane, [&]() __attribute__((always_inline)) {
                                 if (layer < n_layers) load_layer_weights(layer + 1);
                               });
@@ -311,13 +271,8 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   if (channels == 32) {
     constexpr int NB = 16;
     constexpr int kLds = Geo<32, NB>::kLdsBytes;
-    static const int mode = getenv("C4_TOWER_MODE") ? atoi(getenv("C4_TOWER_MODE")) : 2;
-    auto k = mode == 1 ? c4_conv_tower_kernel<32, NB, 1, 256, 2>
-             : mode == 0 ? c4_conv_tower_kernel<32, NB, 0, 256, 2>
-             : mode == 3 ? c4_conv_tower_kernel<32, NB, 0, 768, 1>
-             : mode == 4 ? c4_conv_tower_kernel<32, NB, 0, 512, 1>
-                         : c4_conv_tower_kernel<32, NB, 0, 512, 2>;
-    const int nt = mode == 3 ? 768 : ((mode == 2 || mode == 4) ? 512 : 256);
+    auto k = c4_conv_tower_kernel<32, NB, 512, 2>;   // 8 waves: two per SIMD, measured best (49 -> 32 us)
+    const int nt = 512;
     e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (e == hipSuccess) {
       k<<<dim3((n_boards + NB - 1) / NB), dim3(nt), kLds, (hipStream_t)stream>>>(p);
@@ -326,7 +281,7 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   } else if (channels == 64) {
     constexpr int NB = 8;
     constexpr int kLds = Geo<64, NB>::kLdsBytes;
-    auto k = c4_conv_tower_kernel<64, NB, 0, 256, 1>;
+    auto k = c4_conv_tower_kernel<64, NB, 256, 1>;   // weights alone take 288 registers: one wave per SIMD
     e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (e == hipSuccess) {
       k<<<dim3((n_boards + NB - 1) / NB), dim3(256), kLds, (hipStream_t)stream>>>(p);
@@ -423,18 +378,9 @@ extern "C" int c4_head_out_bf16(const void* hidden_policy_dev, const void* hidde
     return C4_ERR_BAD_ARG;
   if (features % 8 != 0 || policy_row_stride % 8 != 0 || value_row_stride % 8 != 0) return C4_ERR_BAD_ARG;
   if (n_boards == 0) return C4_OK;
-  static const int bpw = getenv("C4_HEAD_BPW") ? atoi(getenv("C4_HEAD_BPW")) : 2;  // boards per wavefront (2 measured best at G = 4096)
-  if (bpw == 4)
-    c4_head_out_kernel<4><<<dim3((n_boards + 15) / 16), dim3(256), 0, (hipStream_t)stream>>>(
-        (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
-        b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
-  else if (bpw == 2)
-    c4_head_out_kernel<2><<<dim3((n_boards + 7) / 8), dim3(256), 0, (hipStream_t)stream>>>(
-        (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
-        b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
-  else
-    c4_head_out_kernel<1><<<dim3((n_boards + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(
-        (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
-        b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
+  constexpr int kBoardsPerWave = 2;   // measured best of 1 / 2 / 4 at 4096 boards
+  c4_head_out_kernel<kBoardsPerWave><<<dim3((n_boards + 4 * kBoardsPerWave - 1) / (4 * kBoardsPerWave)), dim3(256), 0, (hipStream_t)stream>>>(
+      (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
+      b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
   return hipGetLastError() == hipSuccess ? C4_OK : C4_ERR_HIP;
 }
