@@ -9,10 +9,9 @@
 //     lane 7 = bookkeeping); 8 games per wavefront, one wavefront per workgroup so that a
 //     launch of G games spreads over G/8 workgroups (G = 4096 -> 512 workgroups on 256 CUs).
 //   * tree node storage = "children blocks": the 7 children of an expanded node live in ONE
-//     128-byte, 128-byte-aligned block {n, q_penalty, prior, child_block} x 7 (+ a header
-//     entry), so one select level is one cache line read by one 16-byte load per lane, and the
-//     child link needed for the next level arrives with it.  q_no_penalty (never read by
-//     selection, mcts.rs:359-361) lives in a parallel 32-byte row.
+//     128-byte, 128-byte-aligned block {n, q_penalty, q_no_penalty, prior} x 7 + seven 16-bit
+//     child links, so one select level is one cache line read by one 16-byte load per lane, the
+//     child link needed for the next level arrives with it, and a backup touches one sector.
 //   * no parent links: select records the root->leaf path in the slot state and the next
 //     step's backup walks that list with independent loads (no pointer chase).
 //   * positions are not stored in nodes: select replays make_move from the root position.
@@ -40,17 +39,23 @@ namespace {
 // HBM layout
 // ------------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) Entry {
-  uint32_t n;      // visit_count            (mcts.rs:335)
-  float q_pen;     // q_sum_penalty          (mcts.rs:336)
-  float prior;     // initial_policy_value   (mcts.rs:338)
-  uint32_t child;  // block holding this node's children, 0 = not expanded (mcts.rs:339)
+  uint32_t n;     // visit_count            (mcts.rs:335)
+  float q_pen;    // q_sum_penalty          (mcts.rs:336)
+  float q_nopen;  // q_sum_no_penalty       (mcts.rs:337)
+  float prior;    // initial_policy_value   (mcts.rs:338)
 };
+struct __attribute__((aligned(16))) Tail {
+  uint16_t child[7];  // per column: block holding that child's own children, 0 = not expanded (mcts.rs:339)
+  uint16_t legal;     // legal-move mask of the parent position (informational)
+};
+// The 7 children of an expanded node: ONE 128-byte line.  Lane c < 7 of a game's lane group loads
+// entry c, lane 7 the tail, in a single 16-byte-per-lane instruction; a backup touches one entry
+// (one 32-byte sector).  16-bit child links bound an arena to 65 535 blocks per slot.
 struct __attribute__((aligned(128))) Block {
-  Entry e[8];  // e[0..6] = children by column; e[7] = header {legal mask, 0, 0, 0}
+  Entry e[7];
+  Tail t;
 };
-struct __attribute__((aligned(32))) QRow {
-  float q_nopen[8];  // q_sum_no_penalty of the 7 children (mcts.rs:337)
-};
+constexpr uint32_t kMaxBlocksPerSlot = 65535;
 
 constexpr uint32_t kMaxPath = 44;
 struct __attribute__((aligned(256))) Slot {
@@ -70,7 +75,7 @@ struct __attribute__((aligned(256))) Slot {
   uint32_t path[kMaxPath];  // entry refs root..leaf written by select, consumed by backup
 };
 static_assert(sizeof(Slot) == 256, "slot state is two cache lines");
-static_assert(sizeof(Block) == 128 && sizeof(QRow) == 32 && sizeof(c4_sample_rec) == 64, "layout");
+static_assert(sizeof(Block) == 128 && sizeof(Entry) == 16 && sizeof(Tail) == 16 && sizeof(c4_sample_rec) == 64, "layout");
 
 enum : uint32_t { kIdle = 0, kActive = 1 };
 
@@ -98,7 +103,6 @@ struct Globals {             // one small device struct of cross-wave words
 struct Params {
   Slot* slots;
   Block* blocks;
-  QRow* qrows;
   unsigned long long* wave_ctr;  // [n_waves][CTR_N]
   unsigned long long* stamps;    // [2][n_waves][2] start/end device clock of each wavefront, by launch parity
   unsigned long long* clock_acc; // [2] sum of (last end - first start) over launches, number of launches summed
@@ -130,6 +134,17 @@ struct Params {
 C4_DEV uint32_t shfl_u32(uint32_t v, int src_lane) { return (uint32_t)__shfl((int)v, src_lane, 64); }
 C4_DEV float shfl_f32(float v, int src_lane) { return __shfl(v, src_lane, 64); }
 
+// lane `sub` of a group loads its 16 bytes of block `blk`: entry `sub` (sub < 7) or the tail (sub == 7)
+C4_DEV uint4 load_block_lane(const Block* blocks, uint32_t blk, uint32_t sub) {
+  return reinterpret_cast<const uint4*>(blocks + blk)[sub];
+}
+// child link of column `col` out of the tail held by lane 7 of the group (col is group-uniform)
+C4_DEV uint32_t child_link(const uint4& raw, uint32_t col, int gbase) {
+  const uint32_t w = col >> 1;
+  const uint32_t mine = w == 0 ? raw.x : (w == 1 ? raw.y : (w == 2 ? raw.z : raw.w));
+  return (shfl_u32(mine, gbase + 7) >> (16u * (col & 1u))) & 0xFFFFu;
+}
+
 C4_DEV void raise_error(const Params& p, Slot* st, uint32_t g, uint32_t code) {
   st->status = code;
   if (atomicCAS(&p.glob->error, 0u, code) == 0u) p.glob->error_slot = g;
@@ -155,14 +170,11 @@ C4_DEV void publish_leaf_model(const Params& p, uint32_t g, unsigned long long o
 }
 
 // Put game `ordinal` on a slot: MctsGame::new_from_pos (mcts.rs:48-56).  Called by all 8 lanes.
-C4_DEV void reset_slot(const Params& p, Slot* st, Block* blocks, QRow* qrows, uint32_t sub, unsigned long long ordinal) {
+C4_DEV void reset_slot(const Params& p, Slot* st, Block* blocks, uint32_t sub, unsigned long long ordinal) {
   const uint64_t m = p.start_mask ? p.start_mask[ordinal] : 0ull;
   const uint64_t v = p.start_value ? p.start_value[ordinal] : 0ull;
   // block 0 holds only the root's own entry (prior 1.0, mcts.rs:49) in column 0
-  Entry e;
-  e.n = 0; e.q_pen = 0.0f; e.prior = (sub == 0) ? 1.0f : 0.0f; e.child = 0;
-  blocks[0].e[sub] = e;
-  qrows[0].q_nopen[sub] = 0.0f;
+  reinterpret_cast<uint4*>(blocks)[sub] = make_uint4(0, 0, 0, sub == 0 ? __float_as_uint(1.0f) : 0u);
   if (sub == 0) {
     st->root_mask = m; st->root_value = v;
     st->leaf_mask = m; st->leaf_value = v;
@@ -187,10 +199,9 @@ __global__ __launch_bounds__(64) void c4_start_kernel(Params p) {
   if (g >= p.n_slots) return;
   Slot* st = p.slots + g;
   Block* blocks = p.blocks + (size_t)g * p.blocks_per_slot;
-  QRow* qrows = p.qrows + (size_t)g * p.blocks_per_slot;
   uint64_t m = 0, v = 0;
   if (g < p.n_games) {
-    reset_slot(p, st, blocks, qrows, sub, g);
+    reset_slot(p, st, blocks, sub, g);
     m = p.start_mask ? p.start_mask[g] : 0ull;
     v = p.start_value ? p.start_value[g] : 0ull;
     if (sub == 0) publish_leaf_model(p, g, g, m);
@@ -248,8 +259,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
 
   if (active) {
     Block* blocks = p.blocks + (size_t)g * p.blocks_per_slot;
-    QRow* qrows = p.qrows + (size_t)g * p.blocks_per_slot;
-
+  
     uint64_t leaf_mask = st->leaf_mask, leaf_value = st->leaf_value;
     uint64_t rmask = st->root_mask, rvalue = st->root_value;
     uint32_t depth = st->depth;
@@ -287,14 +297,10 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       const uint32_t nb = n_blocks;
       if (nb >= p.blocks_per_slot) err = err ? err : C4_ERR_ARENA_OVERFLOW;
       if (!err) {
-        Entry e;                                                              // Node::new, mcts.rs:345-355
-        e.n = (sub == 7) ? legal : 0u;
-        e.q_pen = 0.0f;
-        e.prior = (sub == 7) ? 0.0f : prior;
-        e.child = 0;
-        blocks[nb].e[sub] = e;
-        qrows[nb].q_nopen[sub] = 0.0f;
-        if (sub == 0) blocks[leaf_ref >> 3].e[leaf_ref & 7].child = nb;       // leaf.children = Some(..)
+        // Node::new (mcts.rs:345-355) for the 7 children; lane 7 writes the tail (no links yet)
+        reinterpret_cast<uint4*>(blocks + nb)[sub] =
+            sub < 7 ? make_uint4(0u, 0u, 0u, __float_as_uint(prior)) : make_uint4(0u, 0u, 0u, legal << 16);
+        if (sub == 0) blocks[leaf_ref >> 3].t.child[leaf_ref & 7] = (uint16_t)nb;   // leaf.children = Some(..)
         if (depth == 0) root_block = nb;
         n_blocks = nb + 1;
         c_E = 1;
@@ -312,14 +318,13 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       for (uint32_t d = sub; d <= depth; d += 8) {
         const uint32_t ref = (d < 8) ? path_a : (d < 16 ? path_b : st->path[d]);
         Entry* e = &blocks[ref >> 3].e[ref & 7];
-        float* qn = &qrows[ref >> 3].q_nopen[ref & 7];
         const bool odd = ((depth - d) & 1u) != 0;                             // value negated per step up
         const uint32_t n1 = e->n + 1;
         const float q1 = e->q_pen + (odd ? -v_pen : v_pen);
-        const float q2 = *qn + (odd ? -v_nopen : v_nopen);
+        const float q2 = e->q_nopen + (odd ? -v_nopen : v_nopen);
         e->n = n1;
         e->q_pen = q1;
-        *qn = q2;
+        e->q_nopen = q2;
         if (d == 0) root_n = n1;
       }
       root_n = shfl_u32(root_n, gbase);
@@ -338,8 +343,8 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
         uint32_t retained = p.n_iter;
         if (!rterm) {
           // root_policy (mcts.rs:396-412): child visit counts / their sum
-          const Entry re = blocks[root_block].e[sub];
-          const float cnt = (sub < 7) ? (float)re.n : 0.0f;
+          const uint4 re = load_block_lane(blocks, root_block, sub);
+          const float cnt = (sub < 7) ? (float)re.x : 0.0f;
           float w[7];
           float csum = 0.0f;
           for (int i = 0; i < 7; i++) { w[i] = shfl_f32(cnt, gbase + i); csum = csum + w[i]; }
@@ -366,8 +371,8 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
             if (sub == 7) {
               rec->game_id = st->game_id; rec->mask = rmask; rec->value = rvalue; rec->meta = n_moves;
             }
-            retained = shfl_u32(re.n, gbase + col);
-            const uint32_t child_blk = shfl_u32(re.child, gbase + col);
+            retained = shfl_u32(re.x, gbase + col);
+            const uint32_t child_blk = child_link(re, (uint32_t)col, gbase);
             root_ref = (root_block << 3) | (uint32_t)col;
             root_block = child_blk;
             root_n = retained;
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
           }
           next = ((unsigned long long)shfl_u32((uint32_t)(next >> 32), gbase) << 32) | shfl_u32((uint32_t)next, gbase);
           if (next < p.n_games) {
-            reset_slot(p, st, blocks, qrows, sub, next);
+            reset_slot(p, st, blocks, sub, next);
             __threadfence_block();
             rmask = p.start_mask ? p.start_mask[next] : 0ull;
             rvalue = p.start_value ? p.start_value[next] : 0ull;
@@ -433,17 +438,17 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
           uint64_t m = rmask, v = rvalue;
           uint32_t blk = root_block, np = root_n, d = 0, last_ref = root_ref;
           while (blk != 0 && d + 1 < kMaxPath) {
-            const Entry ce = blocks[blk].e[sub];
+            const uint4 ce = load_block_lane(blocks, blk, sub);   // {n, q_pen, q_nopen, prior} | tail
             const uint32_t legal = c4::legal_mask(m);
             const bool ok = sub < 7 && ((legal >> sub) & 1u);
             float score = 0.0f;
             if (ok) {
               // uct_value (mcts.rs:359-388); c4_logf(1) == 0 makes every first-level score -0+0
-              const float nf = (float)ce.n + 1.0f;
-              const float qv = ce.q_pen / nf;
+              const float nf = (float)ce.x + 1.0f;
+              const float qv = __uint_as_float(ce.y) / nf;
               float ex = c4::c4_logf((float)np) / nf;
               ex = __builtin_sqrtf(ex);
-              ex = ex * (ce.prior + 1e-8f);
+              ex = ex * (__uint_as_float(ce.w) + 1e-8f);
               const float cx = p.c_exploration * ex;
               score = -qv + cx;
             }
@@ -459,8 +464,8 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
               if (take) { bs = os; bi = oi; }
             }
             const uint32_t best = (uint32_t)bi;
-            np = shfl_u32(ce.n, gbase + (int)best);
-            const uint32_t next_blk = shfl_u32(ce.child, gbase + (int)best);
+            np = shfl_u32(ce.x, gbase + (int)best);
+            const uint32_t next_blk = child_link(ce, best, gbase);
             c4::make_move(m, v, best);
             d += 1;
             last_ref = (blk << 3) | best;
@@ -662,7 +667,8 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
   uint64_t bps = cfg->blocks_per_slot;
   if (bps == 0) bps = 43ull * (cfg->n_mcts_iterations ? cfg->n_mcts_iterations : 1) + 8;
   if (bps < 2) bps = 2;
-  if (bps >= (1ull << 29)) { delete s; return fail(C4_ERR_BAD_ARG, "blocks_per_slot too large"); }
+  if (cfg->blocks_per_slot > kMaxBlocksPerSlot) { delete s; return fail(C4_ERR_BAD_ARG, "blocks_per_slot is limited to 65535 (16-bit child links)"); }
+  if (bps > kMaxBlocksPerSlot) bps = kMaxBlocksPerSlot;   // n_mcts_iterations > 1523: overflow is still detected per slot
   s->cfg.blocks_per_slot = (uint32_t)bps;
   const size_t n = cfg->n_slots;
   s->n_waves = (uint32_t)((n + 7) / 8);
@@ -676,7 +682,6 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
   hipError_t e;
   if ((e = hipMalloc(&p.slots, n * sizeof(Slot))) != hipSuccess ||
       (e = hipMalloc(&p.blocks, n * bps * sizeof(Block))) != hipSuccess ||
-      (e = hipMalloc(&p.qrows, n * bps * sizeof(QRow))) != hipSuccess ||
       (e = hipMalloc(&p.wave_ctr, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.glob, sizeof(Globals))) != hipSuccess ||
       (e = hipMalloc(&p.stamps, (size_t)s->n_waves * 4 * sizeof(unsigned long long))) != hipSuccess ||
@@ -684,7 +689,7 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
       (e = hipMalloc(&p.phase, (size_t)s->n_waves * 16 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipHostMalloc(&s->probe_host, sizeof(Globals))) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s->probe_event, hipEventDisableTiming)) != hipSuccess) {
-    std::string msg = std::string("allocating session (") + std::to_string((n * bps * (sizeof(Block) + sizeof(QRow))) >> 20) +
+    std::string msg = std::string("allocating session (") + std::to_string((n * bps * sizeof(Block)) >> 20) +
                       " MiB of tree arena): " + hipGetErrorString(e);
     c4_session_destroy(s);
     return fail(C4_ERR_HIP, msg);
@@ -705,7 +710,7 @@ int c4_session_destroy(c4_session* s) {
   if (!s) return C4_OK;
   (void)hipSetDevice(s->cfg.device);
   if (s->stream) (void)hipStreamSynchronize(s->stream); else (void)hipDeviceSynchronize();
-  (void)hipFree(s->p.slots); (void)hipFree(s->p.blocks); (void)hipFree(s->p.qrows); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob); (void)hipFree(s->p.stamps); (void)hipFree(s->p.clock_acc); (void)hipFree(s->p.phase);
+  (void)hipFree(s->p.slots); (void)hipFree(s->p.blocks); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob); (void)hipFree(s->p.stamps); (void)hipFree(s->p.clock_acc); (void)hipFree(s->p.phase);
   (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts);
   (void)hipFree(s->reqs_dev); (void)hipFree(s->start_mask_dev); (void)hipFree(s->start_value_dev);
   if (s->probe_host) (void)hipHostFree(s->probe_host);
@@ -948,23 +953,21 @@ int c4_session_root_stats(c4_session* s, uint32_t slot, float policy[7], float* 
   HIP_TRY(hipMemcpy(&st, s->p.slots + slot, sizeof st, hipMemcpyDeviceToHost));
   const size_t base = (size_t)slot * s->cfg.blocks_per_slot;
   Block rb;
-  QRow rq;
   HIP_TRY(hipMemcpy(&rb, s->p.blocks + base + (st.root_ref >> 3), sizeof rb, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(&rq, s->p.qrows + base + (st.root_ref >> 3), sizeof rq, hipMemcpyDeviceToHost));
   const Entry& re = rb.e[st.root_ref & 7];
   // mcts.rs:359-367: q_sum / (visit_count as f32 + 1.0)
   const float nf = (float)re.n + 1.0f;
   if (q_penalty) *q_penalty = re.q_pen / nf;
-  if (q_no_penalty) *q_no_penalty = rq.q_nopen[st.root_ref & 7] / nf;
+  if (q_no_penalty) *q_no_penalty = re.q_nopen / nf;
   if (visit_count) *visit_count = re.n;
   if (root_mask) *root_mask = st.root_mask;
   if (root_value) *root_value = st.root_value;
   if (policy) {
     // mcts.rs:396-412
     float cnt[7] = {0, 0, 0, 0, 0, 0, 0}, sum = 0.0f;
-    if (re.child) {
+    if (st.root_block) {
       Block cb;
-      HIP_TRY(hipMemcpy(&cb, s->p.blocks + base + re.child, sizeof cb, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(&cb, s->p.blocks + base + st.root_block, sizeof cb, hipMemcpyDeviceToHost));
       for (int c = 0; c < 7; c++) cnt[c] = (float)cb.e[c].n;
     }
     for (int c = 0; c < 7; c++) sum = sum + cnt[c];

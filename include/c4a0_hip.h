@@ -64,7 +64,8 @@ typedef struct {
 /* Arguments of self_play() (self_play.rs:39-46) that are fixed for a session, plus sizing. */
 typedef struct {
   uint32_t n_slots;           /* games resident on the GPU and advanced in lock-step */
-  uint32_t blocks_per_slot;   /* tree arena per slot, in 7-children blocks; 0 = worst case 43*n_mcts_iterations+8 */
+  uint32_t blocks_per_slot;   /* tree arena per slot, in 128-byte 7-children blocks; 0 = worst case 43*n_mcts_iterations+8;
+                                 at most 65535 (16-bit child links) */
   uint32_t n_mcts_iterations; /* self_play.rs:43 */
   float c_exploration;        /* self_play.rs:44 (f32, as pybridge.rs:26) */
   float c_ply_penalty;        /* self_play.rs:45 */
