@@ -16,8 +16,9 @@
  *   - move sampling RNG (rand 0.10.1 StdRng + WeightedIndex, chacha20 0.10.1): the
  *     crates' source is not in /root/reference and no reference test pins a sampled
  *     move => "PARITY UNPINNED" at this one boundary.  ChaCha block function is
- *     pinned by RFC 7539 / eSTREAM vectors; seed expansion and float sampling are
- *     restated from the crates' documented algorithm.
+ *     pinned by RFC 7539 / eSTREAM vectors and StdRng = ChaCha12 word order by the
+ *     rand crate's own test_stdrng_construction vector; the PCG32 seed expansion
+ *     and the float sampling are restated from the crates' documented algorithm.
  */
 #ifndef C4_ORACLE_H
 #define C4_ORACLE_H

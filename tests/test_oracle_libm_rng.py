@@ -94,6 +94,23 @@ def test_chacha_counter_is_words_12_13():
     assert _words_to_bytes(a)[:16].hex() == "9f07e7be5551387a98ba977c732d080d"
 
 
+def test_stdrng_construction_vector_of_the_rand_crate():
+    """rand's own unit test `test_stdrng_construction` (rand 0.8/0.9 src/rngs/std.rs; the crate is a
+    third-party dependency whose source is NOT in /root/reference, so the vector is quoted from the
+    published crate): StdRng::from_seed([1,0,0,0, 23,0,0,0, 200,1,0,0, 210,30,0,0, 0 x16]).next_u64()
+    == 10719222850664546238, and StdRng::from_rng(that rng).next_u64() == 14064965282130556830.
+    It pins: StdRng = ChaCha12, output = words 0,1,... of block 0 little-endian, and that from_rng
+    consumes the next 32 bytes of the stream as the new seed."""
+    seed = bytes([1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16)
+    w = O.chacha_block(seed, 0, 12)
+    assert w[0] | (w[1] << 32) == 10719222850664546238
+    seed1 = b"".join(struct.pack("<I", x) for x in w[2:10])
+    w1 = O.chacha_block(seed1, 0, 12)
+    assert w1[0] | (w1[1] << 32) == 14064965282130556830
+    for rounds in (8, 20):   # the vector distinguishes the round count
+        assert O.chacha_block(seed, 0, rounds)[0] != w[0]
+
+
 SEED_TABLE = [  # SURVEY Appendix A.1 (independent scratch restatement): seed -> key, first u32, u01
     (0, "ecf273f981b5cd4587f0467306ad6cadd0d0a3e33317e767f29bea72d78a7dfe", 0xCD2C6F7F, 0.8014591932296753),
     (1, "ead81d725d26104e899c3bf842ce782ebad303da9997d2c2120256ac7366fb1b", 0xD3301861, 0.8249526023864746),
