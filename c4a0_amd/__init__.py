@@ -15,3 +15,19 @@ def __getattr__(name):  # torch / the HIP library are loaded on first use of the
         from . import api
         return getattr(api, name)
     raise AttributeError(name)
+
+
+def install_as_c4a0_rust():
+    """Make `import c4a0_rust` resolve to this package and make pickles interchangeable with the
+    reference's: its PyO3 classes are registered under module "c4a0_rust" (pybridge.rs:60,
+    types.rs) and `games.pkl` stores `c4a0_rust.PlayGamesResult` + CBOR state
+    (training.py:48-67).  After this call the reference's training.py / tournament.py run on the
+    GPU generator unmodified, and either side can load the other's pickles."""
+    import sys
+
+    from . import results
+
+    for cls in (results.GameMetadata, results.GameResult, results.PlayGamesResult, results.Sample):
+        cls.__module__ = "c4a0_rust"
+    sys.modules["c4a0_rust"] = sys.modules[__name__]
+    return sys.modules[__name__]

@@ -141,3 +141,33 @@ def test_results_from_records_roundtrip():
     out = results_from_records([GameMetadata(3, 0, 0), GameMetadata(9, 0, 0)], recs, np.array([3, 2], dtype=np.uint32))
     assert [len(r.samples) for r in out.results] == [3, 2]
     assert out.results[1].samples[1].mask == 8 and out.results[0].samples[1].q_penalty == np.float32(-0.5)
+
+
+def test_install_as_c4a0_rust_makes_pickles_interchangeable():
+    """The reference pickles `c4a0_rust.PlayGamesResult` with CBOR bytes as state (pybridge.rs:60,
+    83-92; training.py:48-67).  A pickle written that way -- built here by hand, protocol 2
+    copyreg form -- must load, and ours must carry the same module/class names."""
+    import subprocess
+    import sys
+
+    code = r"""
+import pickle, sys
+sys.path.insert(0, %r)
+import c4a0_amd
+from c4a0_amd import GameMetadata, GameResult, PlayGamesResult, Sample
+mod = c4a0_amd.install_as_c4a0_rust()
+import c4a0_rust
+assert c4a0_rust is mod and c4a0_rust.N_COLS == 7 and c4a0_rust.GameMetadata is GameMetadata
+pgr = PlayGamesResult([GameResult(GameMetadata(5, 0, 0), [Sample(0, 0, [1 / 7] * 7, 0.5, 1.0)])])
+blob = pickle.dumps(pgr, protocol=2)
+assert b"c4a0_rust" in blob and b"PlayGamesResult" in blob
+# what the reference writes: copyreg.__newobj__(c4a0_rust.PlayGamesResult) + BUILD with the CBOR bytes
+ref_style = (b"\x80\x02ccopy_reg\n__newobj__\nq\x00cc4a0_rust\nPlayGamesResult\nq\x01\x85q\x02Rq\x03"
+             + pickle.dumps(pgr.to_cbor(), protocol=2)[2:-1] + b"b.")
+back = pickle.loads(ref_style)
+assert type(back) is PlayGamesResult and back == pgr
+assert pickle.loads(blob) == pgr
+print("ok")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
