@@ -60,6 +60,7 @@ SIGNATURES = {
     "c4_session_destroy": (C.c_int, [_vp]),
     "c4_session_set_games": (C.c_int, [_vp, _P(GameMetadataC), C.c_uint64, _P(C.c_uint64), _P(C.c_uint64)]),
     "c4_session_bind_io": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "c4_session_set_dirichlet": (C.c_int, [_vp, C.c_float, C.c_float]),
     "c4_session_bind_leaf_models": (C.c_int, [_vp, _vp]),
     "c4_session_start": (C.c_int, [_vp]),
     "c4_session_step": (C.c_int, [_vp]),
@@ -81,6 +82,7 @@ SIGNATURES = {
     "c4_apply_temperature": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "c4_conv_tower_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
     "c4_head_out_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "c4_dirichlet": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_uint64, _vp, _vp]),
     "c4_sample_move": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
 }
 

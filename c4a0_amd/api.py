@@ -108,7 +108,7 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
                c_exploration: float, c_ply_penalty: float, py_eval_pos_cb: Optional[Callable] = None, *,
                evaluator: Optional[DeviceEvaluator] = None, device=None, resident_games: Optional[int] = None,
                planes_dtype: Optional[torch.dtype] = None, blocks_per_slot: int = 0,
-               stats: Optional[dict] = None) -> PlayGamesResult:
+               stats: Optional[dict] = None, dirichlet: Optional[tuple] = None) -> PlayGamesResult:
     """Play every game of `reqs` to the end with MCTS self-play on the GPU and return the
     training samples (reference pybridge.rs:20-53).  Results are in `reqs` order (the
     reference's order is thread-finishing order, self_play.rs:116)."""
@@ -137,6 +137,8 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
                          planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot)
     try:
         sess.set_games([(r.game_id, r.player0_id, r.player1_id) for r in reqs])
+        if dirichlet is not None:   # extension: (alpha, epsilon) root noise; the reference has none
+            sess.set_dirichlet(*dirichlet)
         if evaluator is None:
             p0 = np.array([r.player0_id for r in reqs], dtype=np.uint64)
             p1 = np.array([r.player1_id for r in reqs], dtype=np.uint64)

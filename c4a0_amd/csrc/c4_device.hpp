@@ -311,6 +311,107 @@ C4_DEV uint32_t rng_first_u32_group(uint64_t state, uint32_t sub, int gbase) {
   return grp_shfl(a, gbase) + 0x61707865u;  // word 0 = column 0's `a` + its constant
 }
 
+// ------------------------------------------------------------------------------------------
+// Dirichlet root noise: BUILD EXTENSION (named by BASELINE.json's north star, absent from the
+// reference).  Specification = oracle/c4_oracle.c `c4o_dirichlet`; this must match it bit for bit.
+// Kept out of line: it is a rare path and must not cost the step kernel registers.
+// ------------------------------------------------------------------------------------------
+struct NoiseStream {
+  uint32_t key[8];
+  uint32_t buf[16];
+  uint64_t counter;
+  int idx;
+};
+
+__device__ __attribute__((noinline)) void noise_refill(NoiseStream& st) {
+  uint32_t x[16];
+  x[0] = 0x61707865; x[1] = 0x3320646e; x[2] = 0x79622d32; x[3] = 0x6b206574;
+  for (int i = 0; i < 8; i++) x[4 + i] = st.key[i];
+  x[12] = (uint32_t)st.counter; x[13] = (uint32_t)(st.counter >> 32); x[14] = 0; x[15] = 0;
+  uint32_t s0[16];
+  for (int i = 0; i < 16; i++) s0[i] = x[i];
+  for (int r = 0; r < 6; r++) {
+    C4_QR(x[0], x[4], x[8], x[12]) C4_QR(x[1], x[5], x[9], x[13]) C4_QR(x[2], x[6], x[10], x[14]) C4_QR(x[3], x[7], x[11], x[15])
+    C4_QR(x[0], x[5], x[10], x[15]) C4_QR(x[1], x[6], x[11], x[12]) C4_QR(x[2], x[7], x[8], x[13]) C4_QR(x[3], x[4], x[9], x[14])
+  }
+  for (int i = 0; i < 16; i++) st.buf[i] = x[i] + s0[i];
+  st.counter += 1;
+  st.idx = 0;
+}
+
+C4_DEV float noise_u01(NoiseStream& st) {
+  if (st.idx == 16) noise_refill(st);
+  const uint32_t u = st.buf[st.idx++];
+  return ((float)(u >> 8) + 0.5f) * 0x1p-24f;
+}
+
+C4_DEV float noise_normal(NoiseStream& st) {  // Marsaglia polar method, second variate discarded
+  for (;;) {
+    const float a = 2.0f * noise_u01(st) - 1.0f;
+    const float b = 2.0f * noise_u01(st) - 1.0f;
+    float s = a * a;
+    const float bb = b * b;
+    s = s + bb;
+    if (s > 0.0f && s < 1.0f) {
+      float t = -2.0f * c4_logf(s);
+      t = t / s;
+      return a * __builtin_sqrtf(t);
+    }
+  }
+}
+
+C4_DEV float noise_gamma(NoiseStream& st, float alpha) {
+  if (alpha == 1.0f) return -c4_logf(noise_u01(st));
+  float boost = 1.0f, a = alpha;
+  if (alpha < 1.0f) {
+    const float lu = c4_logf(noise_u01(st));
+    boost = c4_expf(lu / alpha);
+    a = alpha + 1.0f;
+  }
+  const float d = a - (1.0f / 3.0f);
+  const float c = 1.0f / __builtin_sqrtf(9.0f * d);
+  for (;;) {
+    const float x = noise_normal(st);
+    float v = 1.0f + c * x;
+    if (v <= 0.0f) continue;
+    v = v * v * v;
+    const float u = noise_u01(st);
+    const float lhs = c4_logf(u);
+    const float x2 = x * x;
+    float rhs = 0.5f * x2;
+    rhs = rhs + d;
+    const float dv = d * v;
+    rhs = rhs - dv;
+    const float dlv = d * c4_logf(v);
+    rhs = rhs + dlv;
+    if (lhs < rhs) return (d * v) * boost;
+  }
+}
+
+// eta[7] = Dir(alpha) over the legal columns (0 elsewhere) for (game_id, n_moves)
+__device__ __attribute__((noinline)) void dirichlet_noise(uint64_t game_id, uint32_t n_moves, uint32_t legal, float alpha, float* eta) {
+  NoiseStream st;
+  uint64_t state = (game_id * (uint64_t)(42 + n_moves)) ^ 0x4469726963686C65ull;
+  const uint64_t MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
+  for (int i = 0; i < 8; i++) {
+    state = state * MUL + INC;
+    const uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27);
+    const uint32_t rot = (uint32_t)(state >> 59);
+    st.key[i] = (xs >> rot) | (xs << ((32 - rot) & 31));
+  }
+  st.counter = 0;
+  st.idx = 16;
+  float g[7], sum = 0.0f;
+  for (int c = 0; c < 7; c++) {
+    g[c] = ((legal >> c) & 1u) ? noise_gamma(st, alpha) : 0.0f;
+    sum = sum + g[c];
+  }
+  // every Gamma draw underflowed (tiny alpha): fall back to the uniform point of the simplex
+  const bool degenerate = !(sum > 0.0f) || __builtin_isinf(sum);
+  const float uniform = 1.0f / (float)__popc(legal & 0x7Fu);
+  for (int c = 0; c < 7; c++) eta[c] = ((legal >> c) & 1u) ? (degenerate ? uniform : g[c] / sum) : 0.0f;
+}
+
 // self_play.rs:294-299
 C4_DEV float temperature_for_ply(uint32_t ply) { return ply < 4 ? 4.0f : (ply < 8 ? 2.0f : 1.0f); }
 

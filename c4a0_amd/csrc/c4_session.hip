@@ -126,6 +126,7 @@ struct Params {
   float c_exploration;
   float c_ply_penalty;
   uint32_t flags;
+  float dir_alpha, dir_eps;       // Dirichlet root noise (extension); dir_eps == 0 disables
 };
 
 // ------------------------------------------------------------------------------------------
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(64) void c4_start_kernel(Params p) {
 //   -> gate / move / finish / refill (self_play.rs:283-308, mcts.rs:187-222, 271-313)
 //   -> select (mcts.rs:160-183)  ->  encode the new leaf (c4r.rs:378-392)
 // ------------------------------------------------------------------------------------------
-template <typename PlaneT>
+template <typename PlaneT, bool NOISE>
 __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t sub = lane & 7;
@@ -293,7 +294,19 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       const float ex = c4::c4_expf(logit - mx);
       float sum = 0.0f;                                                       // left-to-right, mcts.rs:432
       for (int i = 0; i < 7; i++) sum = sum + shfl_f32(ex, gbase + i);
-      const float prior = ex / sum;
+      float prior = ex / sum;
+      if (NOISE && p.dir_eps > 0.0f && depth == 0) {
+        // extension: the root is expanded only now -> its children start with noisy priors
+        float eta[7];
+        c4::dirichlet_noise(st->game_id, n_moves, legal, p.dir_alpha, eta);
+        float mine = eta[0];
+        for (int c = 1; c < 7; c++) mine = (sub == (uint32_t)c) ? eta[c] : mine;
+        if (is_legal) {
+          const float keep = (1.0f - p.dir_eps) * prior;
+          const float add = p.dir_eps * mine;
+          prior = keep + add;
+        }
+      }
       const uint32_t nb = n_blocks;
       if (nb >= p.blocks_per_slot) err = err ? err : C4_ERR_ARENA_OVERFLOW;
       if (!err) {
@@ -380,6 +393,21 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
             n_moves += 1;
             c_moves = 1;
             rterm = c4::terminal_state(rmask, rvalue);
+            if (NOISE && p.dir_eps > 0.0f && !rterm && root_block != 0) {
+              // extension: the new root keeps its subtree; fresh noise goes into its children's priors
+              const uint32_t nlegal = c4::legal_mask(rmask);
+              float eta[7];
+              c4::dirichlet_noise(st->game_id, n_moves, nlegal, p.dir_alpha, eta);
+              float mine = eta[0];
+              for (int c = 1; c < 7; c++) mine = (sub == (uint32_t)c) ? eta[c] : mine;
+              if (sub < 7 && ((nlegal >> sub) & 1u)) {
+                Entry* ce = &blocks[root_block].e[sub];
+                const float keep = (1.0f - p.dir_eps) * ce->prior;
+                const float add = p.dir_eps * mine;
+                ce->prior = keep + add;
+              }
+              __threadfence_block();
+            }
           }
         }
         if (!err && rterm) {
@@ -592,6 +620,14 @@ __global__ void k_sample_move(const uint64_t* game_id, const uint32_t* n_moves, 
   if (out_u32) out_u32[i] = u;
 }
 
+__global__ void k_dirichlet(const uint64_t* game_id, const uint32_t* n_moves, const uint32_t* legal, float alpha, uint64_t n, float* eta) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float e[7];
+  c4::dirichlet_noise(game_id[i], n_moves[i], legal[i], alpha, e);
+  for (int c = 0; c < 7; c++) eta[7 * i + c] = e[c];
+}
+
 // K6: pack finished games' records contiguously (one wavefront per game, 4 records per pass)
 __global__ __launch_bounds__(64) void k_pack_samples(const c4_sample_rec* src, const uint32_t* counts,
                                                      const unsigned long long* offsets, uint64_t n_games, c4_sample_rec* dst) {
@@ -769,6 +805,14 @@ int c4_session_bind_io(c4_session* s, void* planes_dev, const float* logprobs_de
   return C4_OK;
 }
 
+int c4_session_set_dirichlet(c4_session* s, float alpha, float epsilon) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  if (!(epsilon >= 0.0f && epsilon <= 1.0f) || (epsilon > 0.0f && !(alpha > 0.0f))) return fail(C4_ERR_BAD_ARG, "need 0 <= epsilon <= 1 and alpha > 0");
+  s->p.dir_alpha = alpha;
+  s->p.dir_eps = epsilon;
+  return C4_OK;
+}
+
 int c4_session_bind_leaf_models(c4_session* s, uint64_t* leaf_models_dev) {
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
   s->p.leaf_models = leaf_models_dev;
@@ -793,10 +837,16 @@ int c4_session_step(c4_session* s) {
   // launch sequence number for the device-clock stamps; frozen at 0 (= no per-launch timing) when
   // timing is off, which is what a launch captured into a HIP graph needs (arguments are baked in)
   s->p.seq = s->timing ? ++s->seq : 0;
-  if (s->cfg.planes_dtype == 0)
-    hipLaunchKernelGGL(c4_step_kernel<float>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
-  else
-    hipLaunchKernelGGL(c4_step_kernel<uint16_t>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+  // the Dirichlet-noise extension is a separate instantiation: the default kernel carries none of its
+  // registers or scratch
+  const bool noise = s->p.dir_eps > 0.0f;
+  if (s->cfg.planes_dtype == 0) {
+    if (noise) hipLaunchKernelGGL((c4_step_kernel<float, true>), dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+    else hipLaunchKernelGGL((c4_step_kernel<float, false>), dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+  } else {
+    if (noise) hipLaunchKernelGGL((c4_step_kernel<uint16_t, true>), dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+    else hipLaunchKernelGGL((c4_step_kernel<uint16_t, false>), dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+  }
   HIP_TRY(hipGetLastError());
   return C4_OK;
 }
@@ -1034,6 +1084,14 @@ int c4_softmax7(const float* logits_dev, const uint32_t* legal_dev, uint64_t n, 
 int c4_apply_temperature(const float* policy_dev, const float* temperature_dev, uint64_t n, float* out_dev, void* stream) {
   if (n == 0) return C4_OK;
   hipLaunchKernelGGL(k_temperature, grid_for(n), dim3(256), 0, (hipStream_t)stream, policy_dev, temperature_dev, n, out_dev);
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+int c4_dirichlet(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, const uint32_t* legal_dev, float alpha, uint64_t n,
+                 float* eta_dev, void* stream) {
+  if (n == 0) return C4_OK;
+  hipLaunchKernelGGL(k_dirichlet, grid_for(n, 64), dim3(64), 0, (hipStream_t)stream, game_id_dev, n_moves_dev, legal_dev, alpha, n, eta_dev);
   HIP_TRY(hipGetLastError());
   return C4_OK;
 }

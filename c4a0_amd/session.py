@@ -82,6 +82,10 @@ class DeviceSession:
                                         C.c_void_p(st.cuda_stream)))
         self._bound_stream = st
 
+    def set_dirichlet(self, alpha: float, epsilon: float):
+        """Extension (not in the reference): Dirichlet noise on the priors of every search root."""
+        check(self.L.c4_session_set_dirichlet(self._h, float(alpha), float(epsilon)))
+
     def bind_leaf_models(self) -> torch.Tensor:
         """int64[n_slots] tensor that start()/step() fill with the model id to evaluate each leaf with."""
         self.leaf_models = torch.zeros(self.n_slots, dtype=torch.int64, device=self.device)

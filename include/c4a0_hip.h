@@ -120,6 +120,13 @@ int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n
 int c4_session_bind_io(c4_session* s, void* planes_dev, const float* logprobs_dev, const float* q_dev,
                        void* stream);
 
+/* Dirichlet root noise -- a BUILD EXTENSION named by BASELINE.json's north star; the reference has
+ * none.  When epsilon > 0, the children of every search root get prior' = (1 - epsilon) * prior +
+ * epsilon * eta with eta ~ Dir(alpha) over the legal columns, drawn from a private ChaCha12 stream
+ * keyed by (game_id, moves played); specification = oracle/c4_oracle.c c4o_dirichlet, matched bit
+ * for bit.  Off (epsilon = 0) by default and in every reference-parity run. */
+int c4_session_set_dirichlet(c4_session* s, float alpha, float epsilon);
+
 /* Multi-model games (player0_id != player1_id: tournaments, tournament.py:112-142): when bound,
  * every start/step also writes, for each slot, the id of the model that must evaluate its leaf
  * (MctsGame::leaf_model_id_to_play, mcts.rs:70-76) to leaf_models_dev [n_slots] (uint64), so the
@@ -191,6 +198,9 @@ int c4_softmax7(const float* logits_dev, const uint32_t* legal_dev, uint64_t n, 
                 uint32_t* out_err_dev, void* stream);
 /* mcts.rs:439-454 */
 int c4_apply_temperature(const float* policy_dev, const float* temperature_dev, uint64_t n, float* out_dev, void* stream);
+/* extension: eta_dev[n][7] = Dir(alpha) noise for (game_id, n_moves, legal mask), see c4_session_set_dirichlet */
+int c4_dirichlet(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, const uint32_t* legal_dev, float alpha, uint64_t n,
+                 float* eta_dev, void* stream);
 /* mcts.rs:214-222 without the tree update: column sampled for (game_id, n_moves, policy, temperature);
  * out_col = -1 on DEGENERATE_POLICY.  out_u32 (may be NULL) = the RNG's first word. */
 int c4_sample_move(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, const float* policy_dev,

@@ -447,6 +447,88 @@ int c4o_sample_move(uint64_t game_id, int n_moves, const float* policy, float te
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Dirichlet root noise -- a BUILD EXTENSION named by BASELINE.json's north star; the reference has
+ * no such code, so there is nothing to be faithful to: this is the
+ * specification, and the HIP kernel must match it bit for bit.  Off unless epsilon > 0.
+ *
+ *   eta = Dir(alpha) over the legal columns of the root, from a private ChaCha12 stream keyed by
+ *   PCG32-expand((game_id * (42 + n_moves)) ^ "Dirichle"), words consumed in order;
+ *   prior'_c = (1 - eps) * prior_c + eps * eta_c for legal c (f32, separate roundings).
+ *   Gamma(a): a == 1: -ln(u);  a > 1: Marsaglia-Tsang with polar-method normals;  a < 1:
+ *   Gamma(a + 1) * exp(ln(u) / a).  u = ((next_u32 >> 8) + 0.5) * 2^-24 in (0, 1).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint8_t key[32]; uint64_t counter; uint32_t buf[16]; int idx; } c4o_stream;
+
+static void stream_init(c4o_stream* st, uint64_t seed) {
+  c4o_seed_from_u64(seed, st->key);
+  st->counter = 0;
+  st->idx = 16;
+}
+static uint32_t stream_u32(c4o_stream* st) {
+  if (st->idx == 16) { c4o_chacha_block(st->key, st->counter++, 12, st->buf); st->idx = 0; }
+  return st->buf[st->idx++];
+}
+static float stream_u01(c4o_stream* st) { return ((float)(stream_u32(st) >> 8) + 0.5f) * 0x1p-24f; }
+
+static float stream_normal(c4o_stream* st) { /* Marsaglia polar method, second variate discarded */
+  for (;;) {
+    float a = 2.0f * stream_u01(st) - 1.0f;
+    float b = 2.0f * stream_u01(st) - 1.0f;
+    float s = a * a;
+    float bb = b * b;
+    s = s + bb;
+    if (s > 0.0f && s < 1.0f) {
+      float t = -2.0f * c4o_logf(s);
+      t = t / s;
+      return a * sqrtf(t);
+    }
+  }
+}
+
+static float stream_gamma(c4o_stream* st, float alpha) {
+  if (alpha == 1.0f) return -c4o_logf(stream_u01(st));
+  float boost = 1.0f;
+  float a = alpha;
+  if (alpha < 1.0f) {
+    float lu = c4o_logf(stream_u01(st));
+    boost = c4o_expf(lu / alpha);
+    a = alpha + 1.0f;
+  }
+  const float d = a - (1.0f / 3.0f);
+  const float c = 1.0f / sqrtf(9.0f * d);
+  for (;;) {
+    float x = stream_normal(st);
+    float v = 1.0f + c * x;
+    if (v <= 0.0f) continue;
+    v = v * v * v;
+    float u = stream_u01(st);
+    float lhs = c4o_logf(u);
+    float x2 = x * x;
+    float rhs = 0.5f * x2;
+    rhs = rhs + d;
+    float dv = d * v;
+    rhs = rhs - dv;
+    float dlv = d * c4o_logf(v);
+    rhs = rhs + dlv;
+    if (lhs < rhs) return (d * v) * boost;
+  }
+}
+
+void c4o_dirichlet(uint64_t game_id, int n_moves, unsigned legal, float alpha, float* eta7) {
+  c4o_stream st;
+  stream_init(&st, (game_id * (uint64_t)(42 + n_moves)) ^ 0x4469726963686C65ull);
+  float g[7], sum = 0.0f;
+  for (int c = 0; c < 7; c++) {
+    g[c] = ((legal >> c) & 1) ? stream_gamma(&st, alpha) : 0.0f;
+    sum = sum + g[c];
+  }
+  /* every Gamma draw underflowed (tiny alpha): fall back to the uniform point of the simplex */
+  const int degenerate = !(sum > 0.0f) || isinf(sum);
+  const float uniform = 1.0f / (float)__builtin_popcount(legal & 0x7Fu);
+  for (int c = 0; c < 7; c++) eta7[c] = ((legal >> c) & 1) ? (degenerate ? uniform : g[c] / sum) : 0.0f;
+}
+
+/* ------------------------------------------------------------------------------------------
  * MCTS game -- rust/src/mcts.rs:27-413.  Rc<RefCell<Node>> graph restated as an arena of
  * nodes addressed by index; a dead Weak parent link is parent == -1.
  * ---------------------------------------------------------------------------------------- */
@@ -471,6 +553,7 @@ struct c4o_game {
   float mv_policy[C4O_MAX_MOVES + 1][7];
   int mv_col[C4O_MAX_MOVES + 1];
   int error;
+  float dir_alpha, dir_eps; /* Dirichlet root noise (extension); eps == 0 disables */
   uint64_t last_select_levels;
   c4o_counters ctr;
 };
@@ -507,6 +590,11 @@ c4o_game* c4o_game_new(const c4o_pos* start, uint64_t game_id, uint64_t p0, uint
   return g;
 }
 
+void c4o_game_set_dirichlet(c4o_game* g, float alpha, float epsilon) {
+  g->dir_alpha = alpha;
+  g->dir_eps = epsilon;
+}
+
 void c4o_game_free(c4o_game* g) {
   if (!g) return;
   free(g->nodes);
@@ -539,6 +627,22 @@ static float node_uct_value(const c4o_game* g, const c4o_node* n, float c_explor
   float q = node_q_with_penalty(n);
   float ex = c_exploration * node_exploration_value(g, n);
   return -q + ex;
+}
+
+/* Extension: mix Dirichlet noise into the priors of the root's children (see c4o_dirichlet). */
+static void apply_root_noise(c4o_game* g) {
+  if (!(g->dir_eps > 0.0f)) return;
+  c4o_node* root = &g->nodes[g->root];
+  if (!root->has_children) return;
+  float eta[7];
+  c4o_dirichlet(g->game_id, g->n_moves, c4o_legal_mask(&root->pos), g->dir_alpha, eta);
+  for (int m = 0; m < 7; m++) {
+    int c = root->child[m];
+    if (c < 0) continue;
+    float keep = (1.0f - g->dir_eps) * g->nodes[c].initial_policy_value;
+    float add = g->dir_eps * eta[m];
+    g->nodes[c].initial_policy_value = keep + add;
+  }
 }
 
 /* mcts.rs:114-132 */
@@ -624,6 +728,7 @@ int c4o_game_on_received_policy(c4o_game* g, const float* logprobs_in, float q_p
     int e = c4o_softmax7(logits, probs);
     if (e) { g->error = e; return e; }
     expand_leaf(g, probs);
+    if (g->leaf == g->root) apply_root_noise(g); /* extension: a root expanded only now */
     backpropagate_value(g, q_penalty, q_no_penalty, 1);
     select_new_leaf(g, c_exploration);
   }
@@ -707,6 +812,7 @@ int c4o_game_make_move(c4o_game* g, int m, float c_exploration) {
   g->n_moves++;
   g->ctr.moves++;
   reroot_compact(g, root->child[m]);
+  apply_root_noise(g); /* extension: the new root starts its search with fresh noise */
   select_new_leaf(g, c_exploration);
   return g->error;
 }
@@ -841,6 +947,12 @@ static inline uint64_t mix64(uint64_t x) {
   return x;
 }
 
+static float g_sp_dir_alpha = 0.0f, g_sp_dir_eps = 0.0f;
+void c4o_self_play_set_dirichlet(float alpha, float epsilon) {
+  g_sp_dir_alpha = alpha;
+  g_sp_dir_eps = epsilon;
+}
+
 int c4o_self_play(const c4o_game_metadata* reqs, uint64_t n_games, int max_nn_batch_size,
                   uint64_t n_mcts_iterations, float c_exploration, float c_ply_penalty,
                   c4o_eval_fn eval, void* eval_ctx, int n_threads,
@@ -860,6 +972,7 @@ int c4o_self_play(const c4o_game_metadata* reqs, uint64_t n_games, int max_nn_ba
   c4o_pos start = {0, 0};
   for (uint64_t i = 0; i < n_games; i++) {
     games[i] = c4o_game_new(&start, reqs[i].game_id, reqs[i].player0_id, reqs[i].player1_id); /* self_play.rs:55-58 */
+    c4o_game_set_dirichlet(games[i], g_sp_dir_alpha, g_sp_dir_eps);
     pending[i] = i;
   }
 

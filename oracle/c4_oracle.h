@@ -88,6 +88,10 @@ uint32_t c4o_rng_first_u32(uint64_t seed);                                /* Std
 int c4o_weighted_index(const float* w7, uint32_t u, int* out_idx);        /* WeightedIndex<f32>::new + sample */
 int c4o_sample_move(uint64_t game_id, int n_moves, const float* policy, float temperature, int* out_col);
 
+/* ---- Dirichlet root noise: BUILD EXTENSION (named by BASELINE.json, absent from the reference) ---- */
+void c4o_dirichlet(uint64_t game_id, int n_moves, unsigned legal, float alpha, float* eta7);
+void c4o_self_play_set_dirichlet(float alpha, float epsilon); /* for games created by c4o_self_play; (0,0) = off */
+
 /* ---- one MCTS game (mcts.rs:27-313) ---- */
 typedef struct c4o_game c4o_game;
 
@@ -112,6 +116,7 @@ typedef struct {
 
 c4o_game* c4o_game_new(const c4o_pos* start, uint64_t game_id, uint64_t player0_id, uint64_t player1_id); /* mcts.rs:48-56 */
 void c4o_game_free(c4o_game* g);
+void c4o_game_set_dirichlet(c4o_game* g, float alpha, float epsilon); /* extension; epsilon 0 = off */
 void c4o_game_root_pos(const c4o_game* g, c4o_pos* out);
 void c4o_game_leaf_pos(const c4o_game* g, c4o_pos* out);
 uint64_t c4o_game_leaf_model_id(const c4o_game* g);                      /* mcts.rs:70-76 */

@@ -102,6 +102,9 @@ def lib() -> C.CDLL:
         "c4o_rng_first_u32": (C.c_uint32, [C.c_uint64]),
         "c4o_weighted_index": (C.c_int, [f32p, C.c_uint32, P(C.c_int)]),
         "c4o_sample_move": (C.c_int, [C.c_uint64, C.c_int, f32p, C.c_float, P(C.c_int)]),
+        "c4o_dirichlet": (None, [C.c_uint64, C.c_int, C.c_uint, C.c_float, f32p]),
+        "c4o_self_play_set_dirichlet": (None, [C.c_float, C.c_float]),
+        "c4o_game_set_dirichlet": (None, [C.c_void_p, C.c_float, C.c_float]),
         "c4o_game_new": (C.c_void_p, [P(Pos), C.c_uint64, C.c_uint64, C.c_uint64]),
         "c4o_game_free": (None, [C.c_void_p]),
         "c4o_game_root_pos": (None, [C.c_void_p, P(Pos)]),
@@ -245,6 +248,12 @@ def chacha_block(key: bytes, counter: int, rounds: int) -> List[int]:
     return list(out)
 
 
+def dirichlet(game_id: int, n_moves: int, legal: int, alpha: float) -> np.ndarray:
+    out = (C.c_float * 7)()
+    lib().c4o_dirichlet(game_id, n_moves, legal, alpha, out)
+    return np.array(out[:], dtype=np.float32)
+
+
 def hash_eval_pos(mask: int, value: int):
     lg = (C.c_float * 7)()
     a, b = C.c_float(), C.c_float()
@@ -351,7 +360,8 @@ NpEval = Callable[[int, np.ndarray], Tuple[np.ndarray, np.ndarray, np.ndarray]]
 
 
 def self_play(reqs: Sequence[Tuple[int, int, int]], max_nn_batch_size: int, n_mcts_iterations: int,
-              c_exploration: float, c_ply_penalty: float, evaluator="uniform", n_threads: int = 1):
+              c_exploration: float, c_ply_penalty: float, evaluator="uniform", n_threads: int = 1,
+              dirichlet: Tuple[float, float] = (0.0, 0.0)):
     """Oracle restatement of self_play.rs:39-129.
 
     `evaluator`: "uniform" | "zeros" | "hash" (built-in C evaluators) or a Python callable
@@ -390,8 +400,10 @@ def self_play(reqs: Sequence[Tuple[int, int, int]], max_nn_batch_size: int, n_mc
 
         keep = EVAL_FN(_cb)
         fn = C.cast(keep, C.c_void_p)
+    L.c4o_self_play_set_dirichlet(float(dirichlet[0]), float(dirichlet[1]))  # extension; (0, 0) = off
     rc = L.c4o_self_play(arr, n, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty,
                          fn, None, n_threads, out, offs, C.byref(stats))
+    L.c4o_self_play_set_dirichlet(0.0, 0.0)
     if keep is not None and err:
         raise err[0]
     if rc:

@@ -234,3 +234,52 @@ def test_pack_samples_on_device_equals_host_drain(env):
             s.step()
     assert (s.sample_counts() > 0).all()
     s.close()
+
+
+def test_dirichlet_noise_extension_matches_its_specification(env):
+    """Dirichlet root noise is a build extension (BASELINE.json names it; the reference has none):
+    the specification is the oracle's c4o_dirichlet.  The device sampler must equal it bit for bit,
+    whole noisy self-play games must equal the oracle's, and with epsilon = 0 nothing changes."""
+    import ctypes as C
+
+    DeviceSession, O, dev = env
+    from c4a0_amd import _lib
+    from tests.helpers import hash_eval_torch, oracle_samples_by_game, samples_by_game
+
+    L = _lib.lib()
+    rng = np.random.default_rng(2)
+    n = 3000
+    gid = rng.integers(0, 1 << 50, n).astype(np.uint64)
+    gid[:5] = [0, 1, 42, 43, (1 << 64) - 1]
+    nm = rng.integers(0, 42, n).astype(np.uint32)
+    legal = rng.integers(1, 128, n).astype(np.uint32)
+    for alpha in (1.0, 0.3, 0.03, 1.4, 10.0):
+        tg = torch.from_numpy(gid.view(np.int64)).to(dev)
+        tn = torch.from_numpy(nm.view(np.int32)).to(dev)
+        tl = torch.from_numpy(legal.view(np.int32)).to(dev)
+        out = torch.empty((n, 7), dtype=torch.float32, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(L.c4_dirichlet(p(tg), p(tn), p(tl), alpha, n, p(out), None))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for i in range(0, n, 3):
+            want = O.dirichlet(int(gid[i]), int(nm[i]), int(legal[i]), alpha)
+            assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), (alpha, i)
+        assert np.all(np.abs(got.sum(1) - 1.0) < 1e-5) and np.all(got[(legal[:, None] >> np.arange(7)) & 1 == 0] == 0)
+
+    reqs = [(g, 0, 0) for g in [0, 3, 42, 43, 1000, 1001, 1002, 1003, 1004, 1005]]
+    results = {}
+    for name, noise in (("off", None), ("zero", (0.3, 0.0)), ("on", (0.3, 0.25)), ("alpha1", (1.0, 0.5))):
+        s = DeviceSession(4, 20, 6.6, 0.01)
+        s.set_games(reqs)
+        if noise is not None:
+            s.set_dirichlet(*noise)
+        s.run(hash_eval_torch)
+        results[name] = samples_by_game(s.drain_samples())
+        s.close()
+    plain, _ = O.self_play(reqs, 64, 20, 6.6, 0.01, "hash")
+    assert results["off"] == results["zero"] == oracle_samples_by_game(plain)
+    for name, noise in (("on", (0.3, 0.25)), ("alpha1", (1.0, 0.5))):
+        want, _ = O.self_play(reqs, 64, 20, 6.6, 0.01, "hash", dirichlet=noise)
+        assert results[name] == oracle_samples_by_game(want), name
+        assert results[name] != results["off"]

@@ -220,3 +220,30 @@ def test_multi_model_majority():                            # self_play.rs:203-2
 
     res, _ = O.self_play([(0, 1, 2), (1, 2, 1), (2, 1, 2)], 8, 3, 1.4, 0.01, ev)
     assert {m for m, _ in calls} == {1, 2} and len(res) == 3
+
+
+# ---- Dirichlet root noise: build extension (BASELINE.json names it; the reference has none) ----
+def test_dirichlet_extension_basic_properties():
+    for alpha in (0.03, 0.3, 1.0, 1.4, 10.0):
+        for g in range(50):
+            legal = 0x7F if g % 3 else 0b1011101
+            e = O.dirichlet(g, g % 40, legal, alpha)
+            assert abs(float(e.sum(dtype=np.float32)) - 1.0) < 1e-5 and e.min() >= 0.0
+            assert all(e[c] == 0.0 for c in range(7) if not (legal >> c) & 1)
+    # deterministic in (game_id, n_moves); different across moves
+    assert np.array_equal(O.dirichlet(9, 4, 0x7F, 0.3), O.dirichlet(9, 4, 0x7F, 0.3))
+    assert not np.array_equal(O.dirichlet(9, 4, 0x7F, 0.3), O.dirichlet(9, 5, 0x7F, 0.3))
+    # component means of Dir(alpha) over 7 columns are 1/7
+    m = np.mean([O.dirichlet(g + 1, 0, 0x7F, 0.3) for g in range(3000)], axis=0)
+    assert np.all(np.abs(m - 1 / 7) < 0.02)
+
+
+def test_dirichlet_off_by_default_and_changes_games_when_on():
+    reqs = [(i, 0, 0) for i in range(6)]
+    a, _ = O.self_play(reqs, 64, 15, 6.6, 0.01, "hash")
+    b, _ = O.self_play(reqs, 64, 15, 6.6, 0.01, "hash", dirichlet=(0.3, 0.0))
+    c, _ = O.self_play(reqs, 64, 15, 6.6, 0.01, "hash", dirichlet=(0.3, 0.25))
+    d, _ = O.self_play(reqs, 64, 15, 6.6, 0.01, "hash")
+    assert a == b == d and a != c
+    for s in c.values():   # noisy games are still well-formed
+        assert O.terminal_state(O.Pos(s[-1].mask, s[-1].value)) != 0
