@@ -131,8 +131,8 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
             raise KeyError(f"no evaluator for model ids {sorted(missing)}")
 
     n_slots = min(len(reqs), int(resident_games) if resident_games else DEFAULT_RESIDENT_GAMES)
-    if planes_dtype is None:
-        planes_dtype = torch.float32
+    if planes_dtype is None:   # hand a bf16 network bf16 planes (0/1 are exact): no conversion kernel per step
+        planes_dtype = torch.bfloat16 if getattr(evaluator, "dtype", None) == torch.bfloat16 else torch.float32
     sess = DeviceSession(n_slots, n_mcts_iterations, c_exploration, c_ply_penalty, device=device,
                          planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot)
     try:

@@ -273,7 +273,11 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
     constexpr int kLds = Geo<32, NB>::kLdsBytes;
     auto k = c4_conv_tower_kernel<32, NB, 512, 2>;   // 8 waves: two per SIMD, measured best (49 -> 32 us)
     const int nt = 512;
-    e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
+    if (!lds_opt_in) {
+      e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      lds_opt_in = (e == hipSuccess);
+    }
     if (e == hipSuccess) {
       k<<<dim3((n_boards + NB - 1) / NB), dim3(nt), kLds, (hipStream_t)stream>>>(p);
       e = hipGetLastError();
@@ -282,7 +286,11 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
     constexpr int NB = 8;
     constexpr int kLds = Geo<64, NB>::kLdsBytes;
     auto k = c4_conv_tower_kernel<64, NB, 256, 1>;   // weights alone take 288 registers: one wave per SIMD
-    e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
+    if (!lds_opt_in) {
+      e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      lds_opt_in = (e == hipSuccess);
+    }
     if (e == hipSuccess) {
       k<<<dim3((n_boards + NB - 1) / NB), dim3(256), kLds, (hipStream_t)stream>>>(p);
       e = hipGetLastError();
