@@ -57,7 +57,7 @@ struct __attribute__((aligned(128))) Block {
 };
 constexpr uint32_t kMaxBlocksPerSlot = 65535;
 
-constexpr uint32_t kMaxPath = 44;
+constexpr uint32_t kMaxPath = 43;   // root + at most 42 moves below it
 struct __attribute__((aligned(256))) Slot {
   uint64_t root_mask, root_value;  // MctsGame::root position
   uint64_t leaf_mask, leaf_value;  // MctsGame::leaf position (waiting for the evaluator)
@@ -71,7 +71,8 @@ struct __attribute__((aligned(256))) Slot {
   uint32_t n_blocks;    // bump pointer of this slot's arena
   uint32_t n_moves;     // MctsGame::moves.len()
   uint32_t leaf_ref;    // = path[depth], kept in the header so the first line carries it
-  uint32_t pad;
+  uint32_t rng_word;    // first ChaCha12 word for the NEXT move (mcts.rs:215-216), precomputed off the critical path
+  uint32_t rng_for;     // n_moves + 1 the word was computed for; 0 = none
   uint32_t path[kMaxPath];  // entry refs root..leaf written by select, consumed by backup
 };
 static_assert(sizeof(Slot) == 256, "slot state is two cache lines");
@@ -185,6 +186,7 @@ C4_DEV void reset_slot(const Params& p, Slot* st, Block* blocks, uint32_t sub, u
     st->root_ref = 0; st->root_block = 0; st->root_n = 0;
     st->depth = 0; st->n_blocks = 1; st->n_moves = 0;
     st->leaf_ref = 0;
+    st->rng_for = 0;
     st->path[0] = 0;
   }
 }
@@ -257,6 +259,10 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
   const float nn_logit = p.logprobs[(size_t)gs * 7 + (sub < 7 ? sub : 6)];
   const float nn_q = p.q[(size_t)gs * 2 + (sub & 1)];
   bool active = (g < p.n_slots) && (st->status == kActive);
+  // move RNG precompute (see the end of the kernel): what this game will need at its next move
+  bool pre_need = false;
+  uint32_t pre_n_moves = 0;
+  unsigned long long pre_game_id = 0;
 
   if (active) {
     Block* blocks = p.blocks + (size_t)g * p.blocks_per_slot;
@@ -269,6 +275,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     uint32_t root_block = st->root_block;
     uint32_t n_moves = st->n_moves;
     const uint32_t leaf_ref = st->leaf_ref;
+    const uint32_t rng_word = st->rng_word, rng_for = st->rng_for;
     // path entries of this lane's backup levels (sub, sub+8): addresses do not depend on `depth`,
     // so these loads go out together with the header
     const uint32_t path_a = st->path[sub];
@@ -371,7 +378,9 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
           c4::apply_temperature_group(pol, temperature, tp, sub, gbase);
           C4_STAMP(10, (uint32_t)tp[0]);
           const uint64_t seed = st->game_id * (uint64_t)(42 + n_moves);
-          const int col = c4::weighted_index(tp, c4::rng_first_u32_group(seed, sub, gbase));
+          // the word was normally computed in an earlier, uncontended step (end of this kernel)
+          const uint32_t u32 = (rng_for == n_moves + 1) ? rng_word : c4::rng_first_u32_group(seed, sub, gbase);
+          const int col = c4::weighted_index(tp, u32);
           C4_STAMP(11, (uint32_t)col);
           if (col < 0) {
             err = C4_ERR_DEGENERATE_POLICY;
@@ -514,6 +523,9 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
               publish_leaf_model(p, g, st->ordinal, m);
             }
             C4_STAMP(6, d);
+            pre_need = (c_moves != 0) || (rng_for != n_moves + 1);   // after a move / refill the stored word is stale
+            pre_n_moves = n_moves;
+            pre_game_id = st->game_id;
             // ---------------- leaf -> evaluator input (c4r.rs:378-392) ----------------------
             for (uint32_t e = sub; e < C4_PLANES_LEN; e += 8)
               store_plane<PlaneT>(p.planes, (size_t)g * C4_PLANES_LEN + e, c4::plane_bit(m, v, e));
@@ -537,6 +549,14 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     add = sub == CTR_SKIPPED ? c_skipped : add;
     add = sub == CTR_SAMPLES ? c_samples : add;
     if (add) atomicAdd(&p.wave_ctr[(size_t)blockIdx.x * CTR_N + sub], add);
+  }
+  // ---------------- move RNG, off the critical path ------------------------------------------
+  // The launch lasts as long as its slowest wavefront, and that is one with a MOVING game.  The
+  // ChaCha12 word a game will need at its next move depends only on (game_id, moves played), so it
+  // is computed here, in a step where no game of this wavefront moved, and kept in the slot.
+  if (__ballot(c_moves != 0) == 0ull && pre_need) {
+    const uint32_t w = c4::rng_first_u32_group(pre_game_id * (uint64_t)(42 + pre_n_moves), sub, gbase);
+    if (sub == 0) { st->rng_word = w; st->rng_for = pre_n_moves + 1; }
   }
   C4_STAMP(8, 0);
   if (lane == 0 && p.seq) {
