@@ -84,7 +84,11 @@ def cpu_baseline(net, device, n_iter: int, threads: int, budget_s: float = 20.0)
     while dt < budget_s / 2 and n_games < 32768:
         n_games *= 2 if dt > budget_s / 8 else 4
         dt, st = run(n_games)
-    return {"value": n_games / dt, "unit": "games/s", "cores": threads, "kind": "port",
+    # context: the tree path alone on the host cores (uniform evaluator, no network at all)
+    t0 = time.perf_counter()
+    _r, st_u = O.self_play([(i, 0, 0) for i in range(2048)], 4096, n_iter, 6.6, 0.01, "uniform", n_threads=threads)
+    tree_only = st_u["sims"] / (time.perf_counter() - t0)
+    return {"value": n_games / dt, "unit": "games/s", "cores": threads, "kind": "port", "tree_only_sims_per_s": tree_only,
             "sample": f"{n_games} games, n_mcts_iterations={n_iter}, C oracle (OpenMP x{threads}) + the same bf16 ResNet on the GPU via the numpy callback round trip; {dt:.1f} s",
             "sims_per_s": st["sims"] / dt}
 

@@ -22,7 +22,10 @@ import torch
 from .results import GameMetadata, PlayGamesResult, results_from_records
 from .session import DeviceEvaluator, DeviceSession
 
-DEFAULT_RESIDENT_GAMES = 16384
+# Games advanced in lock-step per step.  Measured on MI355X (4x32 network): 16 384 games as ONE resident
+# batch take 2.3 s (the step count is set by the longest game, most slots idle at the end), the same
+# games through 4 096 slots that are refilled as games finish take well under half of that.
+DEFAULT_RESIDENT_GAMES = 4096
 
 
 def _planes_from_bits(mask: np.ndarray, value: np.ndarray) -> np.ndarray:
@@ -31,6 +34,13 @@ def _planes_from_bits(mask: np.ndarray, value: np.ndarray) -> np.ndarray:
     p0 = ((value[:, None] >> bits) & np.uint64(1)).astype(np.float32)
     p1 = (((mask & ~value)[:, None] >> bits) & np.uint64(1)).astype(np.float32)
     return np.concatenate([p0, p1], axis=1).reshape(-1, 2, 6, 7)
+
+
+def _popcount64(x: np.ndarray) -> np.ndarray:
+    x = x - ((x >> np.uint64(1)) & np.uint64(0x5555555555555555))
+    x = (x & np.uint64(0x3333333333333333)) + ((x >> np.uint64(2)) & np.uint64(0x3333333333333333))
+    x = (x + (x >> np.uint64(4))) & np.uint64(0x0F0F0F0F0F0F0F0F)
+    return (x * np.uint64(0x0101010101010101)) >> np.uint64(56)
 
 
 class _CallbackEvaluator:
@@ -51,11 +61,16 @@ class _CallbackEvaluator:
         act = np.nonzero(status == 1)[0]
         if act.size:
             p0, p1 = self.slot_models(ordinal[act])
-            ply = np.array([bin(int(m)).count("1") for m in mask[act]], dtype=np.int64)
-            model = np.where(ply % 2 == 0, p0, p1)  # mcts.rs:70-76
-            keys = np.stack([model.astype(np.uint64), mask[act], value[act]], axis=1)
-            uniq, inv = np.unique(keys, axis=0, return_inverse=True)
-            inv = inv.reshape(-1)
+            am, av = mask[act], value[act]
+            model = np.where(_popcount64(am) % np.uint64(2) == 0, p0, p1).astype(np.uint64)  # mcts.rs:70-76
+            # unique (model, position) rows and the inverse map: lexsort + run boundaries
+            order = np.lexsort((av, am, model))
+            sm, sv, so = am[order], av[order], model[order]
+            first = np.ones(order.size, dtype=bool)
+            first[1:] = (sm[1:] != sm[:-1]) | (sv[1:] != sv[:-1]) | (so[1:] != so[:-1])
+            uniq = np.stack([so[first], sm[first], sv[first]], axis=1)
+            inv = np.empty(order.size, dtype=np.int64)
+            inv[order] = np.cumsum(first) - 1
             ulp = np.zeros((uniq.shape[0], 7), dtype=np.float32)
             uq = np.zeros((uniq.shape[0], 2), dtype=np.float32)
             for mid in np.unique(uniq[:, 0]):

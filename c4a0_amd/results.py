@@ -74,6 +74,14 @@ class Sample:
         self.q_penalty = np.float32(q_penalty)
         self.q_no_penalty = np.float32(q_no_penalty)
 
+    @classmethod
+    def _from_row(cls, recs: np.ndarray, pol: np.ndarray, i: int) -> "Sample":
+        s = cls.__new__(cls)
+        s.mask, s.value = int(recs["mask"][i]), int(recs["value"][i])
+        s.policy = pol[i].copy()
+        s.q_penalty, s.q_no_penalty = recs["q_penalty"][i], recs["q_no_penalty"][i]
+        return s
+
     def flip_h(self) -> "Sample":  # types.rs:115-122
         return Sample(flip_h_bits(self.mask), flip_h_bits(self.value), self.policy[::-1].copy(), self.q_penalty, self.q_no_penalty)
 
@@ -227,7 +235,58 @@ class PlayGamesResult:
     rocksdb cache (rust/src/solver.rs) -- out of scope, raises NotImplementedError."""
 
     def __init__(self, results: Iterable[GameResult] = ()):  # pybridge.rs:67-70: empty constructor for unpickling
-        self.results: List[GameResult] = list(results)
+        self._results: List[GameResult] = list(results)
+        self._lazy = None   # (reqs, records, counts) straight from the GPU; objects are built on first access
+
+    @classmethod
+    def _from_records(cls, reqs: Sequence[GameMetadata], recs: np.ndarray, counts: np.ndarray) -> "PlayGamesResult":
+        out = cls()
+        out._lazy = (list(reqs), recs, np.asarray(counts))
+        return out
+
+    @property
+    def results(self) -> List[GameResult]:
+        """`Vec<GameResult>` (pybridge.rs:61-62).  A GPU run hands over ~300 k samples per second of
+        play; the per-sample Python objects are only built when somebody asks for them."""
+        if self._lazy is not None:
+            reqs, recs, counts = self._lazy
+            self._lazy = None
+            out, off = [], 0
+            pol = recs["policy"]
+            for meta, n in zip(reqs, counts.tolist()):
+                samples = [Sample._from_row(recs, pol, i) for i in range(off, off + n)]
+                off += n
+                out.append(GameResult(meta, samples))
+            self._results = out
+        return self._results
+
+    @results.setter
+    def results(self, value):
+        self._lazy = None
+        self._results = list(value)
+
+    def to_arrays(self):
+        """Bulk view for training code (extension; the reference only has per-sample `to_numpy`):
+        (planes float32[N,2,6,7], policy float32[N,7], q_penalty float32[N], q_no_penalty float32[N],
+        game_index int64[N]) over all samples in result order, without building Python objects."""
+        if self._lazy is not None:
+            _reqs, recs, counts = self._lazy
+            mask, value = recs["mask"], recs["value"]
+            pol, qp, qn = recs["policy"].copy(), recs["q_penalty"].copy(), recs["q_no_penalty"].copy()
+            gidx = np.repeat(np.arange(len(counts), dtype=np.int64), counts.astype(np.int64))
+        else:
+            ss = [(gi, s) for gi, r in enumerate(self._results) for s in r.samples]
+            mask = np.array([s.mask for _, s in ss], dtype=np.uint64)
+            value = np.array([s.value for _, s in ss], dtype=np.uint64)
+            pol = np.array([s.policy for _, s in ss], dtype=np.float32).reshape(-1, 7)
+            qp = np.array([s.q_penalty for _, s in ss], dtype=np.float32)
+            qn = np.array([s.q_no_penalty for _, s in ss], dtype=np.float32)
+            gidx = np.array([gi for gi, _ in ss], dtype=np.int64)
+        bits = np.arange(42, dtype=np.uint64)[None, :]
+        p0 = ((value[:, None] >> bits) & np.uint64(1)).astype(np.float32)
+        p1 = (((mask & ~value)[:, None] >> bits) & np.uint64(1)).astype(np.float32)
+        planes = np.concatenate([p0, p1], axis=1).reshape(-1, 2, N_ROWS, N_COLS)
+        return planes, pol, qp, qn, gidx
 
     # -- serialisation (pybridge.rs:73-92)
     def to_cbor(self) -> bytes:
@@ -281,7 +340,8 @@ class PlayGamesResult:
         return self.to_cbor()
 
     def __setstate__(self, state: bytes) -> None:
-        self.results = PlayGamesResult.from_cbor(state).results
+        self._lazy = None
+        self._results = PlayGamesResult.from_cbor(state).results
 
     # -- pybridge.rs:95-106
     def __add__(self, other: "PlayGamesResult") -> "PlayGamesResult":
@@ -306,6 +366,9 @@ class PlayGamesResult:
         raise NotImplementedError("score_policies needs the external c4solver binary and book (reference rust/src/solver.rs); out of scope")
 
     def unique_positions(self) -> int:  # pybridge.rs:150-157
+        if self._lazy is not None:
+            recs = self._lazy[1]
+            return int(np.unique(np.stack([recs["mask"], recs["value"]], axis=1), axis=0).shape[0]) if len(recs) else 0
         return len({(s.mask, s.value) for r in self.results for s in r.samples})
 
     def __eq__(self, o):
@@ -313,11 +376,6 @@ class PlayGamesResult:
 
 
 def results_from_records(reqs: Sequence[GameMetadata], recs: np.ndarray, counts: np.ndarray) -> PlayGamesResult:
-    """Build the result list from the packed sample records of `c4_session_drain_samples`
-    (records of finished games in reqs order) and the per-game sample counts."""
-    out, off = [], 0
-    for meta, n in zip(reqs, counts.tolist()):
-        chunk = recs[off:off + n]
-        off += n
-        out.append(GameResult(meta, [Sample(int(r["mask"]), int(r["value"]), r["policy"], r["q_penalty"], r["q_no_penalty"]) for r in chunk]))
-    return PlayGamesResult(out)
+    """Wrap the packed sample records of `c4_session_drain_samples` (records of finished games in
+    reqs order) and the per-game sample counts; `GameResult`/`Sample` objects are created lazily."""
+    return PlayGamesResult._from_records(reqs, recs, counts)

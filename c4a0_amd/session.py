@@ -202,19 +202,30 @@ class DeviceSession:
         self.start()
         steps = 0
         graph = self.capture_steps(evaluator, steps_per_graph) if steps_per_graph > 0 else None
+        # The host enqueues much faster than the GPU executes.  Unthrottled it would run thousands of
+        # steps ahead of the completion probe and the job would keep evaluating idle slots long after
+        # the last game ended, so at most `max_chunks_in_flight` chunks (a graph replay, or
+        # `poll_every` eager steps) are outstanding at any time.
+        max_chunks_in_flight = 2
+        inflight = []
         while True:
             if graph is not None:
                 graph.replay()
                 steps += steps_per_graph
-                check_now = True
+                chunk_end = True
             else:
                 self.evaluate(evaluator)
-                if on_step is not None:
+                if on_step is not None:   # observers see the evaluator outputs before the step consumes them
                     on_step(steps)
                 self.step()
                 steps += 1
-                check_now = steps % poll_every == 0
-            if check_now:
+                chunk_end = steps % poll_every == 0
+            if chunk_end:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                inflight.append(ev)
+                if len(inflight) > max_chunks_in_flight:
+                    inflight.pop(0).synchronize()
                 done, err = self.poll()
                 if err:
                     self.raise_if_device_error()

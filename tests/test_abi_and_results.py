@@ -171,3 +171,34 @@ print("ok")
 """ % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
+
+
+def test_lazy_results_and_bulk_arrays_agree_with_objects():
+    from c4a0_amd import GameMetadata
+    from c4a0_amd.results import PlayGamesResult, results_from_records
+    from c4a0_amd.session import SAMPLE_DTYPE
+
+    rng = np.random.default_rng(0)
+    counts = np.array([3, 0, 5, 2], dtype=np.uint32)
+    n = int(counts.sum())
+    recs = np.zeros(n, dtype=SAMPLE_DTYPE)
+    recs["mask"] = rng.integers(0, 1 << 42, n, dtype=np.uint64)
+    recs["value"] = recs["mask"] & rng.integers(0, 1 << 42, n, dtype=np.uint64)
+    recs["policy"] = rng.random((n, 7), dtype=np.float32)
+    recs["q_penalty"] = rng.random(n, dtype=np.float32)
+    recs["q_no_penalty"] = -recs["q_penalty"]
+    reqs = [GameMetadata(10 + i, 0, 0) for i in range(4)]
+    lazy = results_from_records(reqs, recs, counts)
+    assert lazy._lazy is not None
+    planes, pol, qp, qn, gidx = lazy.to_arrays()                     # no objects built
+    assert lazy._lazy is not None and lazy.unique_positions() == len({(int(m), int(v)) for m, v in zip(recs["mask"], recs["value"])})
+    assert planes.shape == (n, 2, 6, 7) and np.array_equal(gidx, [0, 0, 0, 2, 2, 2, 2, 2, 3, 3])
+    objs = lazy.results                                              # now materialised
+    assert lazy._lazy is None and [len(r.samples) for r in objs] == [3, 0, 5, 2]
+    flat = [s for r in objs for s in r.samples]
+    for i, s in enumerate(flat):
+        p, po, a, b = s.to_numpy()
+        assert np.array_equal(p, planes[i]) and np.array_equal(po, pol[i]) and a == qp[i] and b == qn[i]
+    planes2, pol2, qp2, qn2, gidx2 = lazy.to_arrays()                 # same answer from the object path
+    assert np.array_equal(planes, planes2) and np.array_equal(pol, pol2) and np.array_equal(gidx, gidx2)
+    assert PlayGamesResult.from_cbor(lazy.to_cbor()) == lazy
