@@ -11,15 +11,16 @@
 //
 // Mapping (C = 32 shown; C = 64 doubles the channel groups and halves NB):
 //   * LDS activation image: [channel group of 8][board][padded cell] 16-byte slots.  Boards are
-//     padded to 8 columns (one shared zero column between rows) plus zero rows above and below,
-//     so a 3x3 tap is a constant slot offset 8*dr + dc and needs no bounds test.
+//     padded to 8 columns (one shared zero column between rows) plus a zero row above and below
+//     (shared between consecutive boards), so a 3x3 tap is a constant slot offset 8*dr + dc and
+//     needs no bounds test.
 //   * GEMM orientation: D[co, cell] = sum_k W[co, k] * X[k, cell] with v_mfma_f32_16x16x32_bf16:
 //     A = weights (held in registers for the whole layer), B = activations, one k-step = one tap
 //     x 32 input channels = one ds_read_b128 per lane.  A tile is 16 consecutive padded cells
 //     (two board rows): 16 distinct 16-byte slots per channel group -> bank-conflict free.
 //   * D leaves the MFMA as 4 consecutive output channels per lane for one cell: bias, ReLU and
 //     the residual add happen in registers and go back to LDS as one 8-byte store.
-//   * 4 waves per workgroup (one per SIMD), each owning 1/4 of the tiles of every layer;
+//   * C = 32: 8 waves per workgroup (two per SIMD), each owning 1/8 of the tiles of every layer;
 //     two tiles are in flight per wave so consecutive MFMAs never wait on their accumulator.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,7 +35,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kPCS = 72;      // padded slots per board per channel group (66 used)
+// A board's padded image uses slots 0..65 of its channel-group plane region; consecutive boards are
+// 56 slots apart, so a board's zero row below row 5 IS the next board's zero row above row 0 (slots
+// 57..64 = next board's 1..8).  The two other shared slots are harmless: a board's slot 0 (= the
+// previous board's last cell) is read only as the (-1,-1) tap of a halo-column output that is never
+// stored, and its slot 65 is the next board's always-zero halo column.
+constexpr int kBS = 56;
 constexpr int kTilesPerBoard = 3;
 
 // slot of board cell (row r, column c): rows 1..6 of an 8-wide padded image, +1 so that the
@@ -46,9 +52,13 @@ struct Geo {
   static constexpr int KG = C / 8;                 // channel groups of 8 (16-byte slots)
   static constexpr int MT = C / 16;                // output-channel tiles of 16
   static constexpr int KC = C / 32;                // k-steps per tap
-  static constexpr int kPlane = NB * kPCS;         // slots per channel-group plane
+  static constexpr int kPlane = (NB * kBS + 10 + 15) / 16 * 16;   // slots per channel-group plane
   static constexpr int kBufSlots = KG * kPlane;    // slots per activation buffer
-  static constexpr int kLdsBytes = 2 * kBufSlots * 16;
+  // C = 32: one layer's weight fragments (18 KB) are staged in LDS by DMA a layer ahead; at C = 64
+  // a layer's weights are 72 KB and go from global memory straight to registers
+  static constexpr bool kStageW = (C == 32);
+  static constexpr int kWFrags = 9 * MT * KC;      // 1 KB fragments (64 lanes x 16 bytes) per C -> C layer
+  static constexpr int kLdsBytes = 2 * kBufSlots * 16 + (kStageW ? 2 * kWFrags * 1024 : 0);   // two stages: layers alternate
   static constexpr int kTiles = NB * kTilesPerBoard;
   static_assert((kPlane * 16) % 256 == 0, "channel-group planes must keep the bank phase");
   static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
@@ -73,11 +83,14 @@ struct TowerParams {
 //     as they arrive.  At C = 32 the workgroup runs 8 wavefronts (two per SIMD), so one wavefront's
 //     LDS waits and epilogue overlap the other's MFMAs (measured: better than software-pipelining
 //     a single wavefront per SIMD);
-//   * the NEXT layer's weights are requested after this layer's last epilogue, under the barrier.
-template <int C, int NB, bool kConv0, int TPP, typename WF, typename NextW>
+//   * weights: C = 32 -- the workgroup fetches each layer's 18 KB ONCE, by global->LDS DMA into one of
+//     two stages a whole layer ahead, and every wavefront copies them LDS->registers at the start
+//     of the layer (eight wavefronts each pulling the same 18 KB through the vector L1 cost ~1 us
+//     per layer).  C = 64 -- requested from global memory after this layer's last epilogue.
+template <int C, int NB, bool kConv0, int TPP, typename WF, typename Hook>
 __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4* __restrict__ dst, WF& wf,
                                             const float* __restrict__ bias, bool is_second, int tile_lo, int tile_hi,
-                                            int lane, NextW&& load_next_weights) {
+                                            int lane, Hook&& after_last_pair) {
   using G = Geo<C, NB>;
   constexpr int kSteps = kConv0 ? 3 : 9 * G::KC;        // MFMA k-steps (= B fragments) per tile
   const int li = lane & 15, lg = lane >> 4;
@@ -121,7 +134,7 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
         plane = 4 * kc + lg;
       }
 #pragma unroll
-      for (int u = 0; u < TPP; u++) fr[u][k] = src[(plane * NB + pr.bidx[u]) * kPCS + pr.slot[u] + d];
+      for (int u = 0; u < TPP; u++) fr[u][k] = src[plane * G::kPlane + pr.bidx[u] * kBS + pr.slot[u] + d];
     }
   };
   auto mfmas = [&](Pair& pr, const uint4 (&fr)[TPP][kSteps]) __attribute__((always_inline)) {
@@ -147,7 +160,7 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
         for (int m = 0; m < G::MT; m++) {
           f32x4 v = pr.acc[u][m];
           // 8-byte half of the 16-byte slot of channel group 2 m + lg/2
-          uint2* dp = reinterpret_cast<uint2*>(&dst[((2 * m + (lg >> 1)) * NB + pr.bidx[u]) * kPCS + pr.slot[u]]) + (lg & 1);
+          uint2* dp = reinterpret_cast<uint2*>(&dst[(2 * m + (lg >> 1)) * G::kPlane + pr.bidx[u] * kBS + pr.slot[u]]) + (lg & 1);
           if (is_second) {
             const uint2 old = *dp;   // bf16 x4: widen by shifting into the f32 exponent/mantissa
             const float o0 = __uint_as_float(old.x << 16), o1 = __uint_as_float(old.x & 0xffff0000u);
@@ -170,7 +183,7 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
     __builtin_amdgcn_sched_barrier(0);
     mfmas(pa, f0);
     epilogue(pa);
-    if (tile + TPP >= tile_hi) load_next_weights();   // after the last epilogue: fewer live registers
+    if (tile + TPP >= tile_hi) after_last_pair();      // after the last epilogue: fewer live registers
   }
 }
 
@@ -193,13 +206,32 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   for (int k = 0; k < 3; k++)
 #pragma unroll
     for (int m = 0; m < G::MT; m++) wf[k][m] = p.w0[(k * G::MT + m) * 64 + lane];
+  const int n_layers = 2 * (int)p.n_blocks;
   auto load_layer_weights = [&](int layer) __attribute__((always_inline)) {   // layer >= 1: [t][m][kc][lane]
-    const bf16x8* wl = p.w + (size_t)(layer - 1) * 9 * G::MT * G::KC * 64;
+    const bf16x8* wl = p.w + (size_t)(layer - 1) * G::kWFrags * 64;
 #pragma unroll
     for (int k = 0; k < kWSteps; k++)
 #pragma unroll
       for (int m = 0; m < G::MT; m++) wf[k][m] = wl[(((k / G::KC) * G::MT + m) * G::KC + (k % G::KC)) * 64 + lane];
   };
+  // C = 32: LDS stage for one layer's fragments, same [t][m][kc][lane] order as global memory
+  uint4* Wst = T + G::kBufSlots;
+  auto stage_layer_weights = [&](int layer) __attribute__((always_inline)) {  // global -> LDS DMA, 1 KB per instruction
+    if (layer > n_layers) return;
+    const uint4* wl = reinterpret_cast<const uint4*>(p.w) + (size_t)(layer - 1) * G::kWFrags * 64;
+    for (int c = wave; c < G::kWFrags; c += NT / 64)
+      __builtin_amdgcn_global_load_lds((const void*)(wl + c * 64 + lane),
+                                       (__attribute__((address_space(3))) void*)(Wst + ((layer & 1) * G::kWFrags + c) * 64), 16, 0, 0);
+  };
+  auto fetch_staged_weights = [&](int layer) __attribute__((always_inline)) {
+    const uint4* ws = Wst + (layer & 1) * G::kWFrags * 64;
+#pragma unroll
+    for (int k = 0; k < kWSteps; k++)
+#pragma unroll
+      for (int m = 0; m < G::MT; m++)
+        wf[k][m] = __builtin_bit_cast(bf16x8, ws[(((k / G::KC) * G::MT + m) * G::KC + (k % G::KC)) * 64 + lane]);
+  };
+  if (G::kStageW) stage_layer_weights(1);
 
   // ---- zero both images (halo cells stay zero for the whole kernel) ----
   for (int i = tid; i < 2 * G::kBufSlots; i += NT) X[i] = make_uint4(0, 0, 0, 0);
@@ -212,7 +244,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
     if (g < p.n_boards) {
       const uint32_t v0 = p.planes[(size_t)g * 84 + cell];
       const uint32_t v1 = p.planes[(size_t)g * 84 + 42 + cell];
-      T[b * kPCS + cell_slot(cell / 7, cell % 7)] = make_uint4(v0 | (v1 << 16), 0, 0, 0);
+      T[b * kBS + cell_slot(cell / 7, cell % 7)] = make_uint4(v0 | (v1 << 16), 0, 0, 0);
     }
   }
   __syncthreads();
@@ -222,19 +254,27 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   constexpr int kTilesPerWave = (G::kTiles + kWaves - 1) / kWaves;
   const int tile_lo = wave * kTilesPerWave;
   const int tile_hi = (tile_lo + kTilesPerWave < G::kTiles) ? tile_lo + kTilesPerWave : G::kTiles;
-  const int n_layers = 2 * (int)p.n_blocks;
 
   // conv0: input image (T) -> X
   tower_layer<C, NB, true, TPP>(T, X, wf, p.bias, false, tile_lo, tile_hi, lane, [&]() __attribute__((always_inline)) {
-    if (n_layers >= 1) load_layer_weights(1);
+    if (!G::kStageW && n_layers >= 1) load_layer_weights(1);
   });
+  if (G::kStageW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's share of the staged layer has landed
   __syncthreads();
   for (int layer = 1; layer <= n_layers; layer++) {
     const bool is_second = (layer & 1) == 0;         // second conv of a block: T -> X, += residual
-    tower_layer<C, NB, false, TPP>(is_second ? T : X, is_second ? X : T, wf, p.bias + (size_t)layer * C, is_second, tile_lo,
-                              tile_hi, lane, [&]() __attribute__((always_inline)) {
-                                if (layer < n_layers) load_layer_weights(layer + 1);
-                              });
+    if (G::kStageW) {
+      // the other stage was last read at the start of the previous layer, a barrier ago: refill it
+      // now for the NEXT layer (lands under this layer's MFMAs), then copy this layer's fragments out
+      stage_layer_weights(layer + 1);
+      fetch_staged_weights(layer);
+    }
+    tower_layer<C, NB, false, TPP>(
+        is_second ? T : X, is_second ? X : T, wf, p.bias + (size_t)layer * C, is_second, tile_lo, tile_hi, lane,
+        [&]() __attribute__((always_inline)) {
+          if (!G::kStageW && layer < n_layers) load_layer_weights(layer + 1);
+        });
+    if (G::kStageW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -245,7 +285,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
     const int b = bc / 42, cell = bc - b * 42;
     const uint32_t g = board0 + b;
     if (g < p.n_boards) {
-      const uint4 v = X[(kg * NB + b) * kPCS + cell_slot(cell / 7, cell % 7)];
+      const uint4 v = X[kg * G::kPlane + b * kBS + cell_slot(cell / 7, cell % 7)];
       reinterpret_cast<uint4*>(p.out)[((size_t)g * 42 + cell) * G::KG + kg] = v;
     }
   }
