@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--eager", action="store_true", help="no HIP graph: launch every kernel from the host")
     ap.add_argument("--steps-per-graph", type=int, default=8)
+    ap.add_argument("--one-sim-per-step", action="store_true",
+                    help="A/B knob: C4_FLAG_ONE_SIM_PER_STEP (no same-launch simulation for terminal leaves)")
     ap.add_argument("--instrumented-steps", type=int, default=300, help="event-bracketed launches for the roofline object")
     args = ap.parse_args()
 
@@ -142,7 +144,8 @@ def main():
     torch.manual_seed(1337)
     net = InferenceNet(ConnectFourNet(cfg), device, dtype=torch.bfloat16)
 
-    sess = DeviceSession(G, n_iter, 6.6, 0.01, device=device, planes_dtype=torch.bfloat16)
+    sess = DeviceSession(G, n_iter, 6.6, 0.01, device=device, planes_dtype=torch.bfloat16,
+                         one_sim_per_step=args.one_sim_per_step)
     preroll = args.preroll if args.preroll >= 0 else int(2.0 * 15.0 * n_iter)  # ~2 game lengths of sims
     total_steps = preroll + args.warmup + args.steps + args.instrumented_steps + 64
     sims_per_game_lo = 8 * n_iter  # generous lower bound on sims per game -> upper bound on games needed

@@ -17,6 +17,7 @@ STATUS_NAMES = {
     5: "C4_ERR_ARENA_OVERFLOW", 6: "C4_ERR_NOT_BOUND", 7: "C4_ERR_NO_DEVICE", 8: "C4_ERR_ILLEGAL_MOVE",
 }
 FLAG_NO_MOVES = 1
+FLAG_ONE_SIM_PER_STEP = 2
 MAX_SAMPLES_PER_GAME = 43
 
 

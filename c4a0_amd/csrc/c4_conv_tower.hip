@@ -416,6 +416,84 @@ __global__ __launch_bounds__(256) void c4_head_out_kernel(const uint4* __restric
   }
 }
 
+
+// MFMA form of the same computation (used when F is a multiple of 32 * 7 * 6, i.e. F = 42 * C):
+// a workgroup owns 16 boards; D[board][output] = sum_k X[board][k] * W[output][k] with
+// v_mfma_f32_16x16x32_bf16 (A = 16 boards x 32 features straight from global memory, B = the 7 or 2
+// weight rows, zero-padded to 16 columns).  The feature dimension is split over 6 wavefronts,
+// every wavefront requests all of its operands before the first MFMA (one memory round trip), and
+// the partial tiles meet in LDS.  No cross-lane reduction per output, 16-byte loads only.
+constexpr int kHeadWaves = 6, kHeadSteps = 7;
+__global__ __launch_bounds__(64 * kHeadWaves) void c4_head_out_mfma_kernel(
+    const uint4* __restrict__ hp, const uint4* __restrict__ hv, const uint4* __restrict__ wp, const uint4* __restrict__ wv,
+    const float* __restrict__ bp, const float* __restrict__ bv, uint32_t n_boards, uint32_t f8, uint32_t sp8, uint32_t sv8,
+    float* __restrict__ logprobs, float* __restrict__ q) {
+  __shared__ f32x4 part[kHeadWaves][2][64];
+  __shared__ float tile[2][16][17];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t row = lane & 15, kq = lane >> 4;
+  const uint32_t g0 = blockIdx.x * 16;
+  const uint32_t g = (g0 + row < n_boards) ? g0 + row : n_boards - 1;     // tail rows recompute the last board (never stored)
+  const uint4* xp = hp + (size_t)g * sp8 + kq;
+  const uint4* xv = hv + (size_t)g * sv8 + kq;
+  const uint4* wpl = wp + (size_t)(row < 7 ? row : 0) * f8 + kq;           // B column = output `row`
+  const uint4* wvl = wv + (size_t)(row < 2 ? row : 0) * f8 + kq;
+  const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+  f32x4 accp = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
+  const uint32_t n_iter = f8 / (4 * kHeadSteps * kHeadWaves);
+  for (uint32_t it = 0; it < n_iter; it++) {
+    const uint32_t s0 = (it * kHeadWaves + wave) * kHeadSteps;           // first k-step (of 32 features) of this wavefront
+    uint4 a_p[kHeadSteps], a_v[kHeadSteps], b_p[kHeadSteps], b_v[kHeadSteps];
+#pragma unroll
+    for (int s = 0; s < kHeadSteps; s++) {
+      a_p[s] = xp[4 * (s0 + s)];
+      a_v[s] = xv[4 * (s0 + s)];
+      b_p[s] = row < 7 ? wpl[4 * (s0 + s)] : zero;
+      b_v[s] = row < 2 ? wvl[4 * (s0 + s)] : zero;
+    }
+#pragma unroll
+    for (int s = 0; s < kHeadSteps; s++) {
+      accp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_p[s]), __builtin_bit_cast(bf16x8, b_p[s]), accp, 0, 0, 0);
+      accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_v[s]), __builtin_bit_cast(bf16x8, b_v[s]), accv, 0, 0, 0);
+    }
+  }
+  part[wave][0][lane] = accp;
+  part[wave][1][lane] = accv;
+  __syncthreads();
+  if (wave < 2) {
+    // wavefront 0 finishes the policy tile, wavefront 1 the value tile: lane holds output column
+    // `row` of boards 4 kq .. 4 kq + 3
+    f32x4 sum = part[0][wave][lane];
+#pragma unroll
+    for (int w = 1; w < kHeadWaves; w++) sum += part[w][wave][lane];
+    const float bias = wave == 0 ? (row < 7 ? bp[row] : 0.f) : (row < 2 ? bv[row] : 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; r++) tile[wave][4 * kq + r][row] = sum[r] + bias;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const uint32_t b = threadIdx.x, gb = g0 + b;
+    if (gb < n_boards) {
+      float v[9];
+#pragma unroll
+      for (int o = 0; o < 7; o++) v[o] = tile[0][b][o];
+      v[7] = tile[1][b][0];
+      v[8] = tile[1][b][1];
+      float mx = v[0];
+#pragma unroll
+      for (int o = 1; o < 7; o++) mx = fmaxf(mx, v[o]);
+      float sm = 0.f;
+#pragma unroll
+      for (int o = 0; o < 7; o++) sm += expf(v[o] - mx);
+      const float lse = mx + logf(sm);
+#pragma unroll
+      for (int o = 0; o < 7; o++) logprobs[(size_t)gb * 7 + o] = v[o] - lse;
+      q[(size_t)gb * 2 + 0] = tanhf(v[7]);
+      q[(size_t)gb * 2 + 1] = tanhf(v[8]);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int c4_head_out_bf16(const void* hidden_policy_dev, const void* hidden_value_dev, const void* w_policy_dev,
@@ -426,7 +504,13 @@ extern "C" int c4_head_out_bf16(const void* hidden_policy_dev, const void* hidde
     return C4_ERR_BAD_ARG;
   if (features % 8 != 0 || policy_row_stride % 8 != 0 || value_row_stride % 8 != 0) return C4_ERR_BAD_ARG;
   if (n_boards == 0) return C4_OK;
-  constexpr int kBoardsPerWave = 2;   // measured best of 1 / 2 / 4 at 4096 boards
+  if ((features / 8) % (4 * kHeadSteps * kHeadWaves) == 0) {
+    c4_head_out_mfma_kernel<<<dim3((n_boards + 15) / 16), dim3(64 * kHeadWaves), 0, (hipStream_t)stream>>>(
+        (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
+        b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
+    return hipGetLastError() == hipSuccess ? C4_OK : C4_ERR_HIP;
+  }
+  constexpr int kBoardsPerWave = 2;   // other feature counts: dot-product form (measured best of 1 / 2 / 4 boards per wavefront)
   c4_head_out_kernel<kBoardsPerWave><<<dim3((n_boards + 4 * kBoardsPerWave - 1) / (4 * kBoardsPerWave)), dim3(256), 0, (hipStream_t)stream>>>(
       (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
       b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);

@@ -136,6 +136,18 @@ struct Params {
 C4_DEV uint32_t shfl_u32(uint32_t v, int src_lane) { return (uint32_t)__shfl((int)v, src_lane, 64); }
 C4_DEV float shfl_f32(float v, int src_lane) { return __shfl(v, src_lane, 64); }
 
+// Exchanges inside an 8-lane group without the LDS crossbar (DPP): lane ^ 1, lane ^ 2, and 7 - lane.
+// After the first two every lane of a quad holds the quad's combination, so the mirror step pairs
+// the two quads: three steps reduce a group for any commutative, associative combination.
+template <int kStep>
+C4_DEV uint32_t grp_xchg(uint32_t v) {
+  static_assert(kStep >= 0 && kStep < 3, "three butterfly steps");
+  constexpr int ctrl = kStep == 0 ? 0xB1 /* quad_perm [1,0,3,2] */ : (kStep == 1 ? 0x4E /* quad_perm [2,3,0,1] */ : 0x141 /* row_half_mirror */);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xF, 0xF, true);
+}
+template <int kStep>
+C4_DEV float grp_xchg(float v) { return __uint_as_float(grp_xchg<kStep>(__float_as_uint(v))); }
+
 // lane `sub` of a group loads its 16 bytes of block `blk`: entry `sub` (sub < 7) or the tail (sub == 7)
 C4_DEV uint4 load_block_lane(const Block* blocks, uint32_t blk, uint32_t sub) {
   return reinterpret_cast<const uint4*>(blocks + blk)[sub];
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
 
   if (active) {
     Block* blocks = p.blocks + (size_t)g * p.blocks_per_slot;
-  
+
     uint64_t leaf_mask = st->leaf_mask, leaf_value = st->leaf_value;
     uint64_t rmask = st->root_mask, rvalue = st->root_value;
     uint32_t depth = st->depth;
@@ -274,67 +286,78 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     uint32_t root_ref = st->root_ref;
     uint32_t root_block = st->root_block;
     uint32_t n_moves = st->n_moves;
-    const uint32_t leaf_ref = st->leaf_ref;
+    uint32_t leaf_ref = st->leaf_ref;
     const uint32_t rng_word = st->rng_word, rng_for = st->rng_for;
+    uint32_t ordinal = st->ordinal;
+    unsigned long long game_id = st->game_id;
+    bool fresh = false;                  // the slot took a new game in this launch
     // path entries of this lane's backup levels (sub, sub+8): addresses do not depend on `depth`,
     // so these loads go out together with the header
-    const uint32_t path_a = st->path[sub];
-    const uint32_t path_b = st->path[sub + 8];
+    uint32_t path_a = st->path[sub];
+    uint32_t path_b = st->path[sub + 8];
     uint32_t err = 0;
+    uint32_t root_n = 0;
+    // One simulation per game per launch, plus a second one when the leaf just selected is terminal:
+    // such a leaf needs no evaluator row (mcts.rs:92-98 ignores the network for it), so its value is
+    // backed up here and now instead of idling through an evaluator pass.  The order of a game's
+    // simulations and every value in them is unchanged; C4_FLAG_NO_MOVES / C4_FLAG_ONE_SIM_PER_STEP
+    // keep exactly one.
+    const uint32_t max_sims = (p.flags & (C4_FLAG_NO_MOVES | C4_FLAG_ONE_SIM_PER_STEP)) ? 1u : 2u;
 
     C4_STAMP(1, depth + n_blocks + leaf_ref + path_a + path_b + (uint32_t)leaf_mask);
-    // ---------------- on_received_policy: terminal value or expansion -------------------
-    float v_pen, v_nopen;
-    const uint32_t term = c4::terminal_state(leaf_mask, leaf_value);
-    if (term) {
-      c4::terminal_value(term, leaf_mask, p.c_ply_penalty, v_pen, v_nopen);  // NN output ignored (mcts.rs:92-98)
-    } else {
-      const uint32_t legal = c4::legal_mask(leaf_mask);
-      const bool is_legal = sub < 7 && ((legal >> sub) & 1u);
-      float logit = __uint_as_float(0xff800000u);                             // mask_policy, c4r.rs:272-286
-      if (is_legal) logit = nn_logit;
-      float mx = logit;                                                       // f32::max fold (NaN-ignoring)
-      mx = c4::rust_max(mx, shfl_f32(mx, (int)(lane ^ 1)));
-      mx = c4::rust_max(mx, shfl_f32(mx, (int)(lane ^ 2)));
-      mx = c4::rust_max(mx, shfl_f32(mx, (int)(lane ^ 4)));
-      if (__builtin_isinf(mx)) err = C4_ERR_DEGENERATE_POLICY;                // mcts.rs:421-425
-      const float ex = c4::c4_expf(logit - mx);
-      float sum = 0.0f;                                                       // left-to-right, mcts.rs:432
-      for (int i = 0; i < 7; i++) sum = sum + shfl_f32(ex, gbase + i);
-      float prior = ex / sum;
-      if (NOISE && p.dir_eps > 0.0f && depth == 0) {
-        // extension: the root is expanded only now -> its children start with noisy priors
-        float eta[7];
-        c4::dirichlet_noise(st->game_id, n_moves, legal, p.dir_alpha, eta);
-        float mine = eta[0];
-        for (int c = 1; c < 7; c++) mine = (sub == (uint32_t)c) ? eta[c] : mine;
-        if (is_legal) {
-          const float keep = (1.0f - p.dir_eps) * prior;
-          const float add = p.dir_eps * mine;
-          prior = keep + add;
+#pragma clang loop unroll(disable)
+    for (uint32_t sim = 0; sim < max_sims; sim++) {
+      // ---------------- on_received_policy: terminal value or expansion -------------------
+      float v_pen, v_nopen;
+      const uint32_t term = c4::terminal_state(leaf_mask, leaf_value);
+      if (term) {
+        c4::terminal_value(term, leaf_mask, p.c_ply_penalty, v_pen, v_nopen);  // NN output ignored (mcts.rs:92-98)
+      } else {
+        // only ever reached in the first simulation: a later one starts from a terminal leaf
+        const uint32_t legal = c4::legal_mask(leaf_mask);
+        const bool is_legal = sub < 7 && ((legal >> sub) & 1u);
+        float logit = __uint_as_float(0xff800000u);                             // mask_policy, c4r.rs:272-286
+        if (is_legal) logit = nn_logit;
+        float mx = logit;                                                       // f32::max fold (NaN-ignoring)
+        mx = c4::rust_max(mx, grp_xchg<0>(mx));
+        mx = c4::rust_max(mx, grp_xchg<1>(mx));
+        mx = c4::rust_max(mx, grp_xchg<2>(mx));
+        if (__builtin_isinf(mx)) err = C4_ERR_DEGENERATE_POLICY;                // mcts.rs:421-425
+        const float ex = c4::c4_expf(logit - mx);
+        float sum = 0.0f;                                                       // left-to-right, mcts.rs:432
+        for (int i = 0; i < 7; i++) sum = sum + shfl_f32(ex, gbase + i);
+        float prior = ex / sum;
+        if (NOISE && p.dir_eps > 0.0f && depth == 0) {
+          // extension: the root is expanded only now -> its children start with noisy priors
+          float eta[7];
+          c4::dirichlet_noise(game_id, n_moves, legal, p.dir_alpha, eta);
+          float mine = eta[0];
+          for (int c = 1; c < 7; c++) mine = (sub == (uint32_t)c) ? eta[c] : mine;
+          if (is_legal) {
+            const float keep = (1.0f - p.dir_eps) * prior;
+            const float add = p.dir_eps * mine;
+            prior = keep + add;
+          }
         }
+        const uint32_t nb = n_blocks;
+        if (nb >= p.blocks_per_slot) err = err ? err : C4_ERR_ARENA_OVERFLOW;
+        if (!err) {
+          // Node::new (mcts.rs:345-355) for the 7 children; lane 7 writes the tail (no links yet)
+          reinterpret_cast<uint4*>(blocks + nb)[sub] =
+              sub < 7 ? make_uint4(0u, 0u, 0u, __float_as_uint(prior)) : make_uint4(0u, 0u, 0u, legal << 16);
+          if (sub == 0) blocks[leaf_ref >> 3].t.child[leaf_ref & 7] = (uint16_t)nb;   // leaf.children = Some(..)
+          if (depth == 0) root_block = nb;
+          n_blocks = nb + 1;
+          c_E += 1;
+        }
+        v_pen = shfl_f32(nn_q, gbase);
+        v_nopen = shfl_f32(nn_q, gbase + 1);
       }
-      const uint32_t nb = n_blocks;
-      if (nb >= p.blocks_per_slot) err = err ? err : C4_ERR_ARENA_OVERFLOW;
-      if (!err) {
-        // Node::new (mcts.rs:345-355) for the 7 children; lane 7 writes the tail (no links yet)
-        reinterpret_cast<uint4*>(blocks + nb)[sub] =
-            sub < 7 ? make_uint4(0u, 0u, 0u, __float_as_uint(prior)) : make_uint4(0u, 0u, 0u, legal << 16);
-        if (sub == 0) blocks[leaf_ref >> 3].t.child[leaf_ref & 7] = (uint16_t)nb;   // leaf.children = Some(..)
-        if (depth == 0) root_block = nb;
-        n_blocks = nb + 1;
-        c_E = 1;
-      }
-      v_pen = shfl_f32(nn_q, gbase);
-      v_nopen = shfl_f32(nn_q, gbase + 1);
-    }
+      if (err) break;
 
-    if (err) {
-      if (sub == 0) raise_error(p, st, g, err);
-    } else {
       C4_STAMP(2, n_blocks);
       // ---------------- backpropagate_value: leaf -> root along the recorded path ----------
-      uint32_t root_n = 0;
+      root_n = 0;
       for (uint32_t d = sub; d <= depth; d += 8) {
         const uint32_t ref = (d < 8) ? path_a : (d < 16 ? path_b : st->path[d]);
         Entry* e = &blocks[ref >> 3].e[ref & 7];
@@ -348,8 +371,8 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
         if (d == 0) root_n = n1;
       }
       root_n = shfl_u32(root_n, gbase);
-      c_sims = 1;
-      c_K = depth + 1;
+      c_sims += 1;
+      c_K += depth + 1;
       // stores above are read back below through other lanes of this wave
       C4_STAMP(3, root_n);
       __threadfence_block();
@@ -358,7 +381,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       // ---------------- gate: self_play.rs:283-308 ------------------------------------------
       bool finished = false;
       if (root_n >= p.n_iter && !(p.flags & C4_FLAG_NO_MOVES)) {
-        const size_t rec0 = (size_t)st->ordinal * C4_MAX_SAMPLES_PER_GAME;
+        const size_t rec0 = (size_t)ordinal * C4_MAX_SAMPLES_PER_GAME;
         uint32_t rterm = c4::terminal_state(rmask, rvalue);  // non-zero only for a terminal START position
         uint32_t retained = p.n_iter;
         if (!rterm) {
@@ -377,9 +400,9 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
           float tp[7];
           c4::apply_temperature_group(pol, temperature, tp, sub, gbase);
           C4_STAMP(10, (uint32_t)tp[0]);
-          const uint64_t seed = st->game_id * (uint64_t)(42 + n_moves);
+          const uint64_t seed = game_id * (uint64_t)(42 + n_moves);
           // the word was normally computed in an earlier, uncontended step (end of this kernel)
-          const uint32_t u32 = (rng_for == n_moves + 1) ? rng_word : c4::rng_first_u32_group(seed, sub, gbase);
+          const uint32_t u32 = (!fresh && rng_for == n_moves + 1) ? rng_word : c4::rng_first_u32_group(seed, sub, gbase);
           const int col = c4::weighted_index(tp, u32);
           C4_STAMP(11, (uint32_t)col);
           if (col < 0) {
@@ -391,7 +414,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
             c4_sample_rec* rec = p.samples + rec0 + n_moves;
             if (sub < 7) rec->policy[sub] = pol[sub];
             if (sub == 7) {
-              rec->game_id = st->game_id; rec->mask = rmask; rec->value = rvalue; rec->meta = n_moves;
+              rec->game_id = game_id; rec->mask = rmask; rec->value = rvalue; rec->meta = n_moves;
             }
             retained = shfl_u32(re.x, gbase + col);
             const uint32_t child_blk = child_link(re, (uint32_t)col, gbase);
@@ -400,13 +423,13 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
             root_n = retained;
             c4::make_move(rmask, rvalue, (uint32_t)col);
             n_moves += 1;
-            c_moves = 1;
+            c_moves += 1;
             rterm = c4::terminal_state(rmask, rvalue);
             if (NOISE && p.dir_eps > 0.0f && !rterm && root_block != 0) {
               // extension: the new root keeps its subtree; fresh noise goes into its children's priors
               const uint32_t nlegal = c4::legal_mask(rmask);
               float eta[7];
-              c4::dirichlet_noise(st->game_id, n_moves, nlegal, p.dir_alpha, eta);
+              c4::dirichlet_noise(game_id, n_moves, nlegal, p.dir_alpha, eta);
               float mine = eta[0];
               for (int c = 1; c < 7; c++) mine = (sub == (uint32_t)c) ? eta[c] : mine;
               if (sub < 7 && ((nlegal >> sub) & 1u)) {
@@ -424,7 +447,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
           // reference keeps evaluating that root until it has n visits (self_play.rs:283-301);
           // those sims cannot change the samples (mcts.rs:271-313), so the game is closed now
           // and the skipped sims are counted.
-          c_skipped = (p.n_iter > retained) ? (p.n_iter - retained) : 0;
+          c_skipped += (p.n_iter > retained) ? (p.n_iter - retained) : 0;
           float tq_pen, tq_nopen;
           c4::terminal_value(rterm, rmask, p.c_ply_penalty, tq_pen, tq_nopen);
           // to_result (mcts.rs:271-313): sample i gets +q iff (M - i) is even
@@ -436,102 +459,129 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
           c4_sample_rec* tr = p.samples + rec0 + n_moves;
           if (sub < 7) tr->policy[sub] = 1.0f / 7.0f;                         // UNIFORM_POLICY, mcts.rs:45
           if (sub == 7) {
-            tr->game_id = st->game_id; tr->mask = rmask; tr->value = rvalue;
+            tr->game_id = game_id; tr->mask = rmask; tr->value = rvalue;
             tr->q_penalty = tq_pen; tr->q_no_penalty = tq_nopen; tr->meta = n_moves | (1u << 16);
-            p.sample_counts[st->ordinal] = n_moves + 1;
+            p.sample_counts[ordinal] = n_moves + 1;
           }
-          c_done = 1;
-          c_samples = n_moves + 1;
+          c_done += 1;
+          c_samples += n_moves + 1;
           finished = true;
         }
       }
+      if (err) break;
 
-      if (err) {
-        if (sub == 0) raise_error(p, st, g, err);
-      } else {
-        C4_STAMP(12, root_n);
-        if (finished) {
-          // replace the finished game by the next one of the request list (keeps the batch full)
-          unsigned long long next = 0;
-          if (sub == 0) {
-            atomicAdd(&p.glob->games_done, 1ull);
-            next = atomicAdd(&p.glob->queue_head, 1ull);
-          }
-          next = ((unsigned long long)shfl_u32((uint32_t)(next >> 32), gbase) << 32) | shfl_u32((uint32_t)next, gbase);
-          if (next < p.n_games) {
-            reset_slot(p, st, blocks, sub, next);
-            __threadfence_block();
-            rmask = p.start_mask ? p.start_mask[next] : 0ull;
-            rvalue = p.start_value ? p.start_value[next] : 0ull;
-            root_ref = 0; root_block = 0; root_n = 0; n_blocks = 1; n_moves = 0;
-          } else {
-            active = false;
-            if (sub == 0) { st->status = kIdle; st->ordinal = 0xFFFFFFFFu; }
-          }
+      C4_STAMP(12, root_n);
+      if (finished) {
+        // replace the finished game by the next one of the request list (keeps the batch full)
+        unsigned long long next = 0;
+        if (sub == 0) {
+          atomicAdd(&p.glob->games_done, 1ull);
+          next = atomicAdd(&p.glob->queue_head, 1ull);
         }
-        if (active) {
-          C4_STAMP(5, root_n);
-          // ---------------- select_new_leaf (mcts.rs:160-183) -------------------------------
-          uint64_t m = rmask, v = rvalue;
-          uint32_t blk = root_block, np = root_n, d = 0, last_ref = root_ref;
-          while (blk != 0 && d + 1 < kMaxPath) {
-            const uint4 ce = load_block_lane(blocks, blk, sub);   // {n, q_pen, q_nopen, prior} | tail
-            const uint32_t legal = c4::legal_mask(m);
-            const bool ok = sub < 7 && ((legal >> sub) & 1u);
-            float score = 0.0f;
-            if (ok) {
-              // uct_value (mcts.rs:359-388); c4_logf(1) == 0 makes every first-level score -0+0
-              const float nf = (float)ce.x + 1.0f;
-              const float qv = __uint_as_float(ce.y) / nf;
-              float ex = c4::c4_logf((float)np) / nf;
-              ex = __builtin_sqrtf(ex);
-              ex = ex * (__uint_as_float(ce.w) + 1e-8f);
-              const float cx = p.c_exploration * ex;
-              score = -qv + cx;
-            }
-            // max_by_key keeps the LAST maximum (mcts.rs:165-173); NaN panics (utils.rs:12)
-            const bool isn = ok && (score != score);
-            const unsigned long long nan_ballot = __ballot(isn) >> gbase & 0xFFull;
-            if (nan_ballot && __popc(legal) >= 2) { err = C4_ERR_NAN_IN_TREE; break; }
-            float bs = score; int bi = ok ? (int)sub : -1;
-            for (int off = 1; off < 8; off <<= 1) {
-              const float os = shfl_f32(bs, (int)(lane ^ off));
-              const int oi = (int)shfl_u32((uint32_t)bi, (int)(lane ^ off));
-              const bool take = (oi >= 0) && (bi < 0 || os > bs || (os == bs && oi > bi));
-              if (take) { bs = os; bi = oi; }
-            }
-            const uint32_t best = (uint32_t)bi;
-            np = shfl_u32(ce.x, gbase + (int)best);
-            const uint32_t next_blk = child_link(ce, best, gbase);
-            c4::make_move(m, v, best);
-            d += 1;
-            last_ref = (blk << 3) | best;
-            if (sub == 0) st->path[d] = last_ref;
-            blk = next_blk;
-            c_S += 1;
-          }
-          if (err) {
-            if (sub == 0) raise_error(p, st, g, err);
-          } else {
-            if (sub == 0) {
-              st->root_mask = rmask; st->root_value = rvalue;
-              st->leaf_mask = m; st->leaf_value = v;
-              st->root_ref = root_ref; st->root_block = root_block; st->root_n = root_n;
-              st->depth = d; st->n_blocks = n_blocks; st->n_moves = n_moves;
-              st->path[0] = root_ref;
-              st->leaf_ref = last_ref;
-              publish_leaf_model(p, g, st->ordinal, m);
-            }
-            C4_STAMP(6, d);
-            pre_need = (c_moves != 0) || (rng_for != n_moves + 1);   // after a move / refill the stored word is stale
-            pre_n_moves = n_moves;
-            pre_game_id = st->game_id;
-            // ---------------- leaf -> evaluator input (c4r.rs:378-392) ----------------------
-            for (uint32_t e = sub; e < C4_PLANES_LEN; e += 8)
-              store_plane<PlaneT>(p.planes, (size_t)g * C4_PLANES_LEN + e, c4::plane_bit(m, v, e));
-          }
+        next = ((unsigned long long)shfl_u32((uint32_t)(next >> 32), gbase) << 32) | shfl_u32((uint32_t)next, gbase);
+        if (next < p.n_games) {
+          reset_slot(p, st, blocks, sub, next);
+          __threadfence_block();
+          rmask = p.start_mask ? p.start_mask[next] : 0ull;
+          rvalue = p.start_value ? p.start_value[next] : 0ull;
+          root_ref = 0; root_block = 0; root_n = 0; n_blocks = 1; n_moves = 0;
+          ordinal = (uint32_t)next;
+          game_id = p.reqs[next].game_id;
+          fresh = true;
+        } else {
+          active = false;
+          if (sub == 0) { st->status = kIdle; st->ordinal = 0xFFFFFFFFu; }
+          break;
         }
       }
+      C4_STAMP(5, root_n);
+      // ---------------- select_new_leaf (mcts.rs:160-183) -------------------------------
+      uint64_t m = rmask, v = rvalue;
+      uint32_t blk = root_block, d = 0, last_ref = root_ref;
+      float ln_np = c4::c4_logf((float)root_n);               // ln(parent visits) of the level being scored
+      path_a = (sub == 0) ? root_ref : path_a;                // level 0 of the path = the root's own entry
+      while (blk != 0 && d + 1 < kMaxPath) {
+        const uint4 ce = load_block_lane(blocks, blk, sub);   // {n, q_pen, q_nopen, prior} | tail
+        // Off the dependent chain: every lane fetches ITS child's link out of the tail (lane 7) and
+        // takes ln of ITS child's visit count -- the parent term of the next level if that child wins.
+        const uint32_t t0 = shfl_u32(ce.x, gbase + 7), t1 = shfl_u32(ce.y, gbase + 7);
+        const uint32_t t2 = shfl_u32(ce.z, gbase + 7), t3 = shfl_u32(ce.w, gbase + 7);
+        const uint32_t tw = (sub >> 1) == 0 ? t0 : ((sub >> 1) == 1 ? t1 : ((sub >> 1) == 2 ? t2 : t3));
+        const uint32_t my_link = (tw >> (16u * (sub & 1u))) & 0xFFFFu;
+        const float my_ln = c4::c4_logf((float)ce.x);
+        const uint32_t legal = c4::legal_mask(m);
+        const bool ok = sub < 7 && ((legal >> sub) & 1u);
+        float score = 0.0f;
+        if (ok) {
+          // uct_value (mcts.rs:359-388); c4_logf(1) == 0 makes every first-level score -0+0
+          const float nf = (float)ce.x + 1.0f;
+          const float qv = __uint_as_float(ce.y) / nf;
+          float ex = ln_np / nf;
+          ex = __builtin_sqrtf(ex);
+          ex = ex * (__uint_as_float(ce.w) + 1e-8f);
+          const float cx = p.c_exploration * ex;
+          score = -qv + cx;
+        }
+        // max_by_key keeps the LAST maximum (mcts.rs:165-173); NaN panics (utils.rs:12)
+        const bool isn = ok && (score != score);
+        const unsigned long long nan_ballot = __ballot(isn) >> gbase & 0xFFull;
+        if (nan_ballot && __popc(legal) >= 2) { err = C4_ERR_NAN_IN_TREE; break; }
+        // argmax over the group; the winner's visit count, link and ln travel with it
+        float bs = score, bln = my_ln;
+        int bi = ok ? (int)sub : -1;
+        uint32_t bn = ce.x, bl = my_link;
+#define C4_ARGMAX_STEP(K)                                                                        \
+        {                                                                                        \
+          const float os = grp_xchg<K>(bs), oln = grp_xchg<K>(bln);                              \
+          const int oi = (int)grp_xchg<K>((uint32_t)bi);                                         \
+          const uint32_t on = grp_xchg<K>(bn), ol = grp_xchg<K>(bl);                             \
+          const bool take = (oi >= 0) && (bi < 0 || os > bs || (os == bs && oi > bi));           \
+          bs = take ? os : bs; bi = take ? oi : bi; bn = take ? on : bn;                         \
+          bl = take ? ol : bl; bln = take ? oln : bln;                                           \
+        }
+        C4_ARGMAX_STEP(0) C4_ARGMAX_STEP(1) C4_ARGMAX_STEP(2)
+#undef C4_ARGMAX_STEP
+        const uint32_t best = (uint32_t)bi;
+        ln_np = bln;
+        const uint32_t next_blk = bl;
+        c4::make_move(m, v, best);
+        d += 1;
+        last_ref = (blk << 3) | best;
+        if (sub == 0) st->path[d] = last_ref;
+        path_a = (d == sub) ? last_ref : path_a;               // the lanes keep their own backup levels
+        path_b = (d == sub + 8) ? last_ref : path_b;
+        blk = next_blk;
+        c_S += 1;
+      }
+      if (err) break;
+      leaf_mask = m; leaf_value = v; depth = d; leaf_ref = last_ref;
+      C4_STAMP(6, d);
+      // a terminal leaf needs no evaluator: run its simulation now (second trip only)
+      if (sim + 1 < max_sims && c4::terminal_state(m, v)) {
+        if (depth >= 16) __threadfence_block();                // levels >= 16 are re-read from the slot's path
+        continue;
+      }
+      break;
+    }
+
+    if (err) {
+      if (sub == 0) raise_error(p, st, g, err);
+    } else if (active) {
+      if (sub == 0) {
+        st->root_mask = rmask; st->root_value = rvalue;
+        st->leaf_mask = leaf_mask; st->leaf_value = leaf_value;
+        st->root_ref = root_ref; st->root_block = root_block; st->root_n = root_n;
+        st->depth = depth; st->n_blocks = n_blocks; st->n_moves = n_moves;
+        st->path[0] = root_ref;
+        st->leaf_ref = leaf_ref;
+        publish_leaf_model(p, g, ordinal, leaf_mask);
+      }
+      pre_need = fresh || (rng_for != n_moves + 1);   // after a move / refill the stored word is stale
+      pre_n_moves = n_moves;
+      pre_game_id = game_id;
+      // ---------------- leaf -> evaluator input (c4r.rs:378-392) ----------------------
+      for (uint32_t e = sub; e < C4_PLANES_LEN; e += 8)
+        store_plane<PlaneT>(p.planes, (size_t)g * C4_PLANES_LEN + e, c4::plane_bit(leaf_mask, leaf_value, e));
     }
   }
 

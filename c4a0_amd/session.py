@@ -24,7 +24,7 @@ DeviceEvaluator = Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]
 class DeviceSession:
     def __init__(self, n_slots: int, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float,
                  device: Optional[torch.device] = None, planes_dtype: torch.dtype = torch.float32,
-                 blocks_per_slot: int = 0, no_moves: bool = False):
+                 blocks_per_slot: int = 0, no_moves: bool = False, one_sim_per_step: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("c4a0_amd needs a HIP device: the tree kernels have no CPU fallback")
         self.L = _lib.lib()
@@ -38,7 +38,7 @@ class DeviceSession:
         self.n_mcts_iterations = int(n_mcts_iterations)
         cfg = Config(self.n_slots, int(blocks_per_slot), self.n_mcts_iterations, float(c_exploration),
                      float(c_ply_penalty), 0 if planes_dtype == torch.float32 else 1,
-                     _lib.FLAG_NO_MOVES if no_moves else 0, dev_index)
+                     (_lib.FLAG_NO_MOVES if no_moves else 0) | (_lib.FLAG_ONE_SIM_PER_STEP if one_sim_per_step else 0), dev_index)
         h = C.c_void_p()
         check(self.L.c4_session_create(C.byref(cfg), C.byref(h)))
         self._h = h

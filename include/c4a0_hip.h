@@ -75,6 +75,9 @@ typedef struct {
 } c4_config;
 
 #define C4_FLAG_NO_MOVES 1u   /* never move: mcts.rs test helper `run_mcts` (mcts.rs:469-485) */
+#define C4_FLAG_ONE_SIM_PER_STEP 2u /* exactly one simulation per game per c4_session_step.  Default: a game whose
+                                       freshly selected leaf is terminal (no evaluator needed, mcts.rs:92-98) runs that
+                                       simulation in the same step; samples are identical either way */
 
 /* Device-side counters (the reference's progress bars, self_play.rs:352-381, plus the
  * roofline numerators of SURVEY 8d).  Sums over all games since set_games. */

@@ -112,3 +112,34 @@ def test_graphed_evaluator_matches_eager_and_drives_a_session():
     recs = s.drain_samples()
     assert len(recs) == c["samples"] and set(np.unique(recs["game_id"]).tolist()) == set(range(100))
     s.close()
+
+
+@pytest.mark.parametrize("features,n", [(1344, 1), (1344, 777), (1344, 4096), (2688, 530), (320, 100)])
+def test_head_output_kernel_vs_fp32_reference(features, n):
+    """c4_head_out_bf16 (policy Linear+LogSoftmax, value Linear+Tanh; nn.py:84-85, 98-99): the MFMA
+    form (features = 42 C) and the dot-product form (other sizes) against fp32 PyTorch on the same
+    bf16 operands, with strided hidden activations as the merged first layer produces them."""
+    import ctypes as C
+    from c4a0_amd import _lib
+
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(features + n)
+    both = (torch.randn(n, 2 * features, generator=g) * 0.5).bfloat16().to(dev)   # [policy hidden | value hidden]
+    hp, hv = both[:, :features], both[:, features:]
+    wp = (torch.randn(7, features, generator=g) / features ** 0.5).bfloat16().to(dev)
+    wv = (torch.randn(2, features, generator=g) / features ** 0.5).bfloat16().to(dev)
+    bp = torch.randn(7, generator=g).to(dev)
+    bv = torch.randn(2, generator=g).to(dev)
+    lp = torch.full((n, 7), float("nan"), device=dev)
+    q = torch.full((n, 2), float("nan"), device=dev)
+    _lib.check(L.c4_head_out_bf16(C.c_void_p(hp.data_ptr()), C.c_void_p(hv.data_ptr()), C.c_void_p(wp.data_ptr()),
+                                  C.c_void_p(wv.data_ptr()), C.c_void_p(bp.data_ptr()), C.c_void_p(bv.data_ptr()),
+                                  n, features, hp.stride(0), hv.stride(0), C.c_void_p(lp.data_ptr()), C.c_void_p(q.data_ptr()),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    want_lp = torch.log_softmax(hp.float() @ wp.float().T + bp, dim=1)
+    want_q = torch.tanh(hv.float() @ wv.float().T + bv)
+    # f32 accumulation of exact bf16 products on both sides: only the summation order differs
+    assert (lp - want_lp).abs().max().item() < 2e-4, (lp - want_lp).abs().max().item()
+    assert (q - want_q).abs().max().item() < 2e-4, (q - want_q).abs().max().item()

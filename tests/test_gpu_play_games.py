@@ -138,10 +138,21 @@ def test_device_mode_with_real_network_and_t3_replay_parity():
     got = samples_by_game(s.drain_samples())
     s.close()
 
+    zeros = (np.zeros(7, np.float32).tobytes(), np.zeros(2, np.float32).tobytes())
+
+    def answer(m, v):
+        # the device never shows a terminal leaf to the evaluator (its simulation runs in the launch
+        # that selected it); the reference asks and ignores the answer (mcts.rs:92-98)
+        if (m, v) not in table:
+            assert O.terminal_state(O.Pos(m, v)) != 0, "a non-terminal leaf the device never evaluated"
+            return zeros
+        return table[(m, v)]
+
     def lookup(_model_id, x):
         mask, value = planes_to_pos_np(x)
-        lp = np.stack([np.frombuffer(table[(int(m), int(v))][0], dtype=np.float32) for m, v in zip(mask, value)])
-        q = np.stack([np.frombuffer(table[(int(m), int(v))][1], dtype=np.float32) for m, v in zip(mask, value)])
+        ans = [answer(int(m), int(v)) for m, v in zip(mask, value)]
+        lp = np.stack([np.frombuffer(a[0], dtype=np.float32) for a in ans])
+        q = np.stack([np.frombuffer(a[1], dtype=np.float32) for a in ans])
         return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
 
     want, _ = O.self_play(reqs, 64, 12, 6.6, 0.01, lookup)
