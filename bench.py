@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--one-sim-per-step", action="store_true",
                     help="A/B knob: C4_FLAG_ONE_SIM_PER_STEP (no same-launch simulation for terminal leaves)")
     ap.add_argument("--instrumented-steps", type=int, default=300, help="event-bracketed launches for the roofline object")
+    ap.add_argument("--sessions", type=int, default=2,
+                    help="the resident games are split over this many sessions that replay their HIP graphs "
+                         "concurrently on separate streams (1 = one session, one stream)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,6 +137,7 @@ def main():
     if world > 1 or os.environ.get("C4_BENCH_FORCE_DIST") == "1":  # the env knob exercises the RCCL path at world size 1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")   # only reached without a launcher (the world-size-1 knob above)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig, flops_per_leaf
@@ -144,34 +148,56 @@ def main():
     torch.manual_seed(1337)
     net = InferenceNet(ConnectFourNet(cfg), device, dtype=torch.bfloat16)
 
-    sess = DeviceSession(G, n_iter, 6.6, 0.01, device=device, planes_dtype=torch.bfloat16,
-                         one_sim_per_step=args.one_sim_per_step)
+    P = 1 if args.eager else max(1, min(args.sessions, G))
     preroll = args.preroll if args.preroll >= 0 else int(2.0 * 15.0 * n_iter)  # ~2 game lengths of sims
     total_steps = preroll + args.warmup + args.steps + args.instrumented_steps + 64
     sims_per_game_lo = 8 * n_iter  # generous lower bound on sims per game -> upper bound on games needed
     n_games = int(G * (2 + total_steps / sims_per_game_lo)) + G
-    # ids sharded id % world == rank: rank r plays ids r, r+W, ...
-    sess.set_games([(rank + world * i, 0, 0) for i in range(n_games)])
-    sess.bind()
-    sess.start()
+    # ids sharded id % world == rank: rank r plays ids r, r+W, ...; on the GPU the resident
+    # games are split over P sessions (c4a0_amd.session.run_sessions explains why), session p taking
+    # every P-th of the rank's requests
+    ids = [rank + world * i for i in range(n_games)]
+    sessions, streams, graphs = [], [], []
     U = 1 if args.eager else max(1, args.steps_per_graph)
-    graph = None if args.eager else sess.capture_steps(net, U)
-    if args.eager:
-        sess.set_timing(False)
+    for p in range(P):
+        sp = DeviceSession((G + P - 1 - p) // P, n_iter, 6.6, 0.01, device=device, planes_dtype=torch.bfloat16,
+                           one_sim_per_step=args.one_sim_per_step)
+        sp.set_games([(i, 0, 0) for i in ids[p::P]])
+        st = torch.cuda.Stream(device=device) if P > 1 else torch.cuda.current_stream(device)
+        with torch.cuda.stream(st):
+            sp.bind(st)
+            sp.start()
+        st.synchronize()
+        if args.eager:
+            sp.set_timing(False)
+            graphs.append(None)
+        else:
+            graphs.append(sp.capture_steps(net, U, stream=st if P > 1 else None))
+        sessions.append(sp)
+        streams.append(st)
+
+    def counters():
+        tot = {}
+        for sp in sessions:
+            for k, v in sp.counters().items():   # synchronises that session's stream
+                tot[k] = max(tot.get(k, 0), v) if k in ("error", "error_slot") else tot.get(k, 0) + v
+        return tot
 
     def run_steps(k):
-        """k lock-step rounds: HIP-graph replays of U rounds each, remainder launched eagerly."""
-        if graph is not None:
-            for _ in range(k // U):
-                graph.replay()
-            k = k % U
-        for _ in range(k):
-            sess.evaluate(net)
-            sess.step()
+        """k lock-step rounds of every session: HIP-graph replays of U rounds each, remainder launched eagerly."""
+        for _ in range(k // U if graphs[0] is not None else 0):
+            for st, g in zip(streams, graphs):
+                with torch.cuda.stream(st):
+                    g.replay()
+        for _ in range(k % U if graphs[0] is not None else k):
+            for sp, st in zip(sessions, streams):
+                with torch.cuda.stream(st):
+                    sp.evaluate(net)
+                    sp.step()
 
     run_steps(preroll)
     run_steps(args.warmup)
-    c0 = sess.counters()  # synchronises the stream
+    c0 = counters()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -181,29 +207,32 @@ def main():
     if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
-    c1 = sess.counters()
+    c1 = counters()
     if c1["error"]:
         sys.exit(f"device error {c1['error']} in slot {c1['error_slot']}")
     d = {k: c1[k] - c0[k] for k in c1 if k not in ("error", "error_slot")}
     elapsed = t1 - t0
 
-    # ---- instrumented segment right after the timed steps (same steady state): the step kernel
-    # bracketed by HIP events on its stream, and timed on the device clock inside the kernel.
-    # (Inside the graph-replayed region nothing can be bracketed per launch.)
+    # ---- instrumented segment right after the timed steps (same steady state): the step kernel of
+    # session 0 bracketed by HIP events on its stream, and timed on the device clock inside the
+    # kernel; the other sessions wait.  (Inside the graph-replayed region nothing can be bracketed
+    # per launch.)
     n_inst = max(1, min(args.steps, args.instrumented_steps))
+    sess, st0 = sessions[0], streams[0]
     sess.set_timing(True)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_inst)]
     ci0 = sess.counters()
-    for a_ev, b_ev in ev:
-        sess.evaluate(net)
-        a_ev.record()
-        sess.step()
-        b_ev.record()
+    with torch.cuda.stream(st0):
+        for a_ev, b_ev in ev:
+            sess.evaluate(net)
+            a_ev.record(st0)
+            sess.step()
+            b_ev.record(st0)
     torch.cuda.synchronize()
     ci1 = sess.counters()
     if ci1["error"]:
         sys.exit(f"device error {ci1['error']} in slot {ci1['error_slot']}")
-    if ci1["games_started"] >= n_games:
+    if any(sp.counters()["games_started"] >= sp.n_games for sp in sessions):
         sys.exit("bench ran out of queued games; raise n_games")
     di = {k: ci1[k] - ci0[k] for k in ci1 if k not in ("error", "error_slot")}
     step_kernel_ms = sum(a_ev.elapsed_time(b_ev) for a_ev, b_ev in ev)
@@ -217,7 +246,7 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             tg0 = time.perf_counter()
-            local = sess.pack_samples_device()
+            local = torch.cat([sp.pack_samples_device() for sp in sessions], dim=0)
             parts = all_gather_records(local)
             torch.cuda.synchronize()
             tg1 = time.perf_counter()
@@ -253,7 +282,6 @@ def main():
             except Exception:
                 traffic = None
         fl = flops_per_leaf(cfg)
-        nn_s = max(1e-9, elapsed - dev_s * args.steps)
         out = {
             "metric": "self-play games/sec (and MCTS sims/sec) at n_mcts=100",
             "value": games / elapsed_max,
@@ -270,7 +298,8 @@ def main():
             "config": {"workload": f"BASELINE config 2 per GPU: {G} concurrent games, n_mcts_iterations={n_iter}, "
                                    f"{cfg.n_residual_blocks}-block/{cfg.conv_filter_size}-ch ResNet bf16, c_exploration=6.6, c_ply_penalty=0.01",
                        "games_per_gpu": G, "n_mcts_iterations": n_iter, "parallelism": f"games sharded id%{world}",
-                       "evaluator": "eager" if args.eager else f"hip-graph x{U} steps (evaluator + step kernel)", "preroll_steps": preroll,
+                       "evaluator": "eager" if args.eager else f"hip-graph x{U} steps (evaluator + step kernel)",
+                       "concurrent_sessions": P, "games_per_session": [sp.n_slots for sp in sessions], "preroll_steps": preroll,
                        "tree_dtype": "u64 bitboards + f32 UCT"},
             "sims_per_s": sims / elapsed_max,
             "ref_equivalent_sims_per_s": (sims + skipped) / elapsed_max,
@@ -282,15 +311,15 @@ def main():
                          "avg_launch_us": avg_kernel_s * 1e6,
                          "device_clock": {"avg_kernel_us": dev_s * 1e6, "achieved": achieved_dev, "frac": achieved_dev / HBM_PEAK_GBPS,
                                           "note": "in-kernel s_memrealtime stamps; the HIP-event bracket adds the dispatch and completion latency of one launch"},
-                         "launches_measured": n_inst,
+                         "launches_measured": n_inst, "games_per_launch": sess.n_slots,
                          "algorithmic_bytes_per_launch": ab["total"] / n_inst,
                          "bytes_per_sim": {k: v / max(1, di["sims"]) for k, v in ab.items()},
                          "S_per_sim": di["select_levels"] / max(1, di["sims"]), "K_per_sim": di["backup_nodes"] / max(1, di["sims"]),
                          "E_per_sim": di["expansions"] / max(1, di["sims"])},
-            "nn": {"bound": "mfma", "flops_per_leaf": fl, "achieved": fl * G * args.steps / nn_s / 1e12,
+            "nn": {"bound": "mfma", "flops_per_leaf": fl, "achieved": fl * G * args.steps / elapsed / 1e12,
                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": fl * G * args.steps / nn_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                   "note": "wall time of the timed steps minus step-kernel device time; includes launch gaps"},
+                   "frac": fl * G * args.steps / elapsed / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                   "note": "evaluator FLOPs over the WHOLE wall time of the timed steps (tree kernels and launch gaps included): a lower bound on the evaluator's own rate"},
         }
         if allgather is not None:
             out["sample_allgather"] = allgather
@@ -300,7 +329,8 @@ def main():
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    sess.close()
+    for sp in sessions:
+        sp.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -123,7 +123,8 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
                c_exploration: float, c_ply_penalty: float, py_eval_pos_cb: Optional[Callable] = None, *,
                evaluator: Optional[DeviceEvaluator] = None, device=None, resident_games: Optional[int] = None,
                planes_dtype: Optional[torch.dtype] = None, blocks_per_slot: int = 0,
-               stats: Optional[dict] = None, dirichlet: Optional[tuple] = None) -> PlayGamesResult:
+               stats: Optional[dict] = None, dirichlet: Optional[tuple] = None,
+               concurrent_sessions: Optional[int] = None) -> PlayGamesResult:
     """Play every game of `reqs` to the end with MCTS self-play on the GPU and return the
     training samples (reference pybridge.rs:20-53).  Results are in `reqs` order (the
     reference's order is thread-finishing order, self_play.rs:116)."""
@@ -148,6 +149,20 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
     n_slots = min(len(reqs), int(resident_games) if resident_games else DEFAULT_RESIDENT_GAMES)
     if planes_dtype is None:   # hand a bf16 network bf16 planes (0/1 are exact): no conversion kernel per step
         planes_dtype = torch.bfloat16 if getattr(evaluator, "dtype", None) == torch.bfloat16 else torch.float32
+    metas = [GameMetadata(r.game_id, r.player0_id, r.player1_id) for r in reqs]
+    graph_safe = evaluator is not None and not multi and getattr(evaluator, "graph_safe", False)
+    # Device evaluators that are pure device code: the resident games are split over sessions that run
+    # concurrently on their own streams (session.run_sessions), two by default when each half still
+    # fills the GEMMs.  Which session plays a game does not change its samples.
+    parts = int(concurrent_sessions) if concurrent_sessions else (2 if graph_safe and n_slots >= 2048 else 1)
+    if parts > 1 and not graph_safe:
+        raise TypeError("concurrent_sessions > 1 needs a graph-safe device evaluator (c4a0_amd.nn.InferenceNet)")
+    parts = max(1, min(parts, n_slots))
+    if parts > 1:
+        recs, counts = _play_concurrently(reqs, parts, n_slots, n_mcts_iterations, c_exploration, c_ply_penalty, evaluator,
+                                          device, planes_dtype, blocks_per_slot, dirichlet, stats)
+        return results_from_records(metas, recs, counts)
+
     sess = DeviceSession(n_slots, n_mcts_iterations, c_exploration, c_ply_penalty, device=device,
                          planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot)
     try:
@@ -162,19 +177,62 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
         elif multi:
             steps = sess.run(_MultiModelEvaluator(sess, evaluator))
         else:
-            ev = evaluator
             # a c4a0_amd.nn.InferenceNet is pure device code: replay it and the step kernel from a HIP graph
-            spg = 8 if getattr(evaluator, "graph_safe", False) else 0
-            steps = sess.run(ev, steps_per_graph=spg)
+            steps = sess.run(evaluator, steps_per_graph=8 if graph_safe else 0)
         counts = sess.sample_counts()
         recs = sess.drain_samples()
         if stats is not None:
             stats.update(sess.counters())
             stats["steps"] = steps
             stats["n_slots"] = n_slots
+            stats["concurrent_sessions"] = 1
     finally:
         sess.close()
-    return results_from_records([GameMetadata(r.game_id, r.player0_id, r.player1_id) for r in reqs], recs, counts)
+    return results_from_records(metas, recs, counts)
+
+
+def _play_concurrently(reqs, parts, n_slots, n_mcts_iterations, c_exploration, c_ply_penalty, evaluator, device,
+                       planes_dtype, blocks_per_slot, dirichlet, stats):
+    """Session p plays requests p, p + parts, ...; records and counts come back in request order."""
+    from .session import SAMPLE_DTYPE, run_sessions
+
+    sessions = []
+    try:
+        for p in range(parts):
+            mine = reqs[p::parts]
+            slots = min(len(mine), (n_slots + parts - 1 - p) // parts)
+            s = DeviceSession(max(1, slots), n_mcts_iterations, c_exploration, c_ply_penalty, device=device,
+                              planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot)
+            sessions.append(s)
+            s.set_games([(r.game_id, r.player0_id, r.player1_id) for r in mine])
+            if dirichlet is not None:
+                s.set_dirichlet(*dirichlet)
+        steps = run_sessions(sessions, evaluator, steps_per_graph=8)
+        counts = np.zeros(len(reqs), dtype=np.uint32)
+        part_counts = [s.sample_counts() for s in sessions]
+        for p in range(parts):
+            counts[p::parts] = part_counts[p]
+        starts = np.concatenate([[0], np.cumsum(counts, dtype=np.int64)])      # first record of request i in the merged array
+        recs = np.zeros(int(starts[-1]), dtype=SAMPLE_DTYPE)
+        for p, s in enumerate(sessions):
+            r = s.drain_samples()
+            c = part_counts[p].astype(np.int64)
+            src0 = np.concatenate([[0], np.cumsum(c)])[:-1]
+            dst = np.repeat(starts[:-1][p::parts] - src0, c) + np.arange(len(r), dtype=np.int64)
+            recs[dst] = r
+        if stats is not None:
+            tot = {}
+            for s in sessions:
+                for k, v in s.counters().items():
+                    tot[k] = tot.get(k, 0) + v if k not in ("error", "error_slot") else max(tot.get(k, 0), v)
+            stats.update(tot)
+            stats["steps"] = max(steps)
+            stats["n_slots"] = sum(s.n_slots for s in sessions)
+            stats["concurrent_sessions"] = parts
+    finally:
+        for s in sessions:
+            s.close()
+    return recs, counts
 
 
 def run_tui(*_a, **_k):

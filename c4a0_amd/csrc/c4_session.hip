@@ -89,8 +89,15 @@ enum : uint32_t { kIdle = 0, kActive = 1 };
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                       \
     if (lane == 0) p.phase[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime() + ((force) & 0);  \
   } while (0)
+// stamp by whichever lane is active first (second trip of the simulation loop: lane 0's game may have left it)
+#define C4_STAMP_ANY(i)                                                                             \
+  do {                                                                                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                       \
+    if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) p.phase[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();  \
+  } while (0)
 #else
 #define C4_STAMP(i, force) do { } while (0)
+#define C4_STAMP_ANY(i) do { } while (0)
 #endif
 enum : int { CTR_SIMS = 0, CTR_S, CTR_K, CTR_E, CTR_MOVES, CTR_DONE, CTR_SKIPPED, CTR_SAMPLES, CTR_N };
 
@@ -305,6 +312,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     const uint32_t max_sims = (p.flags & (C4_FLAG_NO_MOVES | C4_FLAG_ONE_SIM_PER_STEP)) ? 1u : 2u;
 
     C4_STAMP(1, depth + n_blocks + leaf_ref + path_a + path_b + (uint32_t)leaf_mask);
+#define C4_STAMP_TRIP1(i, force) do { if (sim == 0) C4_STAMP(i, force); } while (0)
 #pragma clang loop unroll(disable)
     for (uint32_t sim = 0; sim < max_sims; sim++) {
       // ---------------- on_received_policy: terminal value or expansion -------------------
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       }
       if (err) break;
 
-      C4_STAMP(2, n_blocks);
+      C4_STAMP_TRIP1(2, n_blocks);
       // ---------------- backpropagate_value: leaf -> root along the recorded path ----------
       root_n = 0;
       for (uint32_t d = sub; d <= depth; d += 8) {
@@ -374,9 +382,9 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       c_sims += 1;
       c_K += depth + 1;
       // stores above are read back below through other lanes of this wave
-      C4_STAMP(3, root_n);
+      C4_STAMP_TRIP1(3, root_n);
       __threadfence_block();
-      C4_STAMP(4, root_n);
+      C4_STAMP_TRIP1(4, root_n);
 
       // ---------------- gate: self_play.rs:283-308 ------------------------------------------
       bool finished = false;
@@ -396,15 +404,15 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
           // make_random_move (mcts.rs:214-222); the 7 columns' logf/expf and the 4 ChaCha columns
           // run on the game's own lanes instead of 8 redundant copies
           const float temperature = c4::temperature_for_ply((uint32_t)__popcll(rmask));
-          C4_STAMP(9, (uint32_t)pol[0]);
+          C4_STAMP_TRIP1(9, (uint32_t)pol[0]);
           float tp[7];
           c4::apply_temperature_group(pol, temperature, tp, sub, gbase);
-          C4_STAMP(10, (uint32_t)tp[0]);
+          C4_STAMP_TRIP1(10, (uint32_t)tp[0]);
           const uint64_t seed = game_id * (uint64_t)(42 + n_moves);
           // the word was normally computed in an earlier, uncontended step (end of this kernel)
           const uint32_t u32 = (!fresh && rng_for == n_moves + 1) ? rng_word : c4::rng_first_u32_group(seed, sub, gbase);
           const int col = c4::weighted_index(tp, u32);
-          C4_STAMP(11, (uint32_t)col);
+          C4_STAMP_TRIP1(11, (uint32_t)col);
           if (col < 0) {
             err = C4_ERR_DEGENERATE_POLICY;
           } else if (!((c4::legal_mask(rmask) >> col) & 1u)) {
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       }
       if (err) break;
 
-      C4_STAMP(12, root_n);
+      C4_STAMP_TRIP1(12, root_n);
       if (finished) {
         // replace the finished game by the next one of the request list (keeps the batch full)
         unsigned long long next = 0;
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
           break;
         }
       }
-      C4_STAMP(5, root_n);
+      C4_STAMP_TRIP1(5, root_n);
       // ---------------- select_new_leaf (mcts.rs:160-183) -------------------------------
       uint64_t m = rmask, v = rvalue;
       uint32_t blk = root_block, d = 0, last_ref = root_ref;
@@ -555,8 +563,9 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       }
       if (err) break;
       leaf_mask = m; leaf_value = v; depth = d; leaf_ref = last_ref;
-      C4_STAMP(6, d);
+      C4_STAMP_TRIP1(6, d);
       // a terminal leaf needs no evaluator: run its simulation now (second trip only)
+      if (sim == 1) C4_STAMP_ANY(13);
       if (sim + 1 < max_sims && c4::terminal_state(m, v)) {
         if (depth >= 16) __threadfence_block();                // levels >= 16 are re-read from the slot's path
         continue;
@@ -564,6 +573,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       break;
     }
 
+#undef C4_STAMP_TRIP1
     if (err) {
       if (sub == 0) raise_error(p, st, g, err);
     } else if (active) {

@@ -101,14 +101,17 @@ class DeviceSession:
     def set_timing(self, enable: bool):
         check(self.L.c4_session_set_timing(self._h, 1 if enable else 0))
 
-    def capture_steps(self, evaluator: DeviceEvaluator, steps_per_graph: int = 8) -> "torch.cuda.CUDAGraph":
+    def capture_steps(self, evaluator: DeviceEvaluator, steps_per_graph: int = 8,
+                      stream: Optional[torch.cuda.Stream] = None) -> "torch.cuda.CUDAGraph":
         """Capture `steps_per_graph` x (evaluator, step kernel) into one HIP graph.
 
         The evaluator must write into the session's bound tensors without host synchronisation
         (c4a0_amd.nn.InferenceNet does).  Per-launch device-clock timing is switched off (its
-        sequence number would be frozen in the graph).  Replay with `graph.replay()`."""
+        sequence number would be frozen in the graph).  Replay with `graph.replay()` on `stream`
+        (default: the current stream), to which the session stays bound.  Sessions that replay
+        concurrently must each be captured on their own stream: library workspaces are per stream."""
         self.set_timing(False)
-        main = torch.cuda.current_stream(self.device)
+        main = stream if stream is not None else torch.cuda.current_stream(self.device)
         # warm the evaluator up outside the capture (library handles, autotuned kernels)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(main)
@@ -119,7 +122,7 @@ class DeviceSession:
         main.wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=stream):
             self.bind(torch.cuda.current_stream(self.device))
             for _ in range(steps_per_graph):
                 self.evaluate(evaluator)
@@ -240,6 +243,57 @@ class DeviceSession:
         if c["error"]:
             raise C4Error(c["error"], f"raised on device by slot {c['error_slot']}")
         return steps
+
+
+def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator, steps_per_graph: int = 8,
+                 max_chunks_in_flight: int = 2) -> List[int]:
+    """Play the games of several sessions of one device to completion CONCURRENTLY, each session
+    replaying its own HIP graph of (evaluator, step kernel) rounds on its own stream.
+
+    Why: one step of one session is a strict chain evaluator -> step kernel, and several links of it
+    (the step kernel, the heads' output kernel, the tower's prologue) are latency-bound and leave
+    most of the chip idle.  With the resident games split over two sessions, one half's latency-bound
+    kernels run under the other half's GEMMs.  A game's samples do not depend on which session or
+    slot plays it.  `evaluator` must be pure device code writing into the bound tensors
+    (graph_safe, e.g. c4a0_amd.nn.InferenceNet); it is shared (weights are read-only, activations
+    live in each graph's own pool).  Returns the steps each session ran."""
+    dev = sessions[0].device
+    streams = [torch.cuda.Stream(device=dev) for _ in sessions]
+    cur = torch.cuda.current_stream(dev)
+    graphs = []
+    for s, st in zip(sessions, streams):
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            s.bind(st)
+            s.start()
+        st.synchronize()
+        graphs.append(s.capture_steps(evaluator, steps_per_graph, stream=st))
+    steps = [0] * len(sessions)
+    live = [s.n_games > 0 for s in sessions]
+    inflight: List[List[torch.cuda.Event]] = [[] for _ in sessions]
+    while any(live):
+        for i, (s, st, g) in enumerate(zip(sessions, streams, graphs)):
+            if not live[i]:
+                continue
+            with torch.cuda.stream(st):
+                g.replay()
+                ev = torch.cuda.Event()
+                ev.record(st)
+                steps[i] += steps_per_graph
+                inflight[i].append(ev)
+                if len(inflight[i]) > max_chunks_in_flight:   # bounded host run-ahead, as in DeviceSession.run
+                    inflight[i].pop(0).synchronize()
+                done, err = s.poll()
+            if err:
+                torch.cuda.synchronize(dev)
+                s.raise_if_device_error()
+            if done >= s.n_games:
+                live[i] = False
+    torch.cuda.synchronize(dev)
+    for s in sessions:
+        s.set_timing(True)
+        s.raise_if_device_error()
+    return steps
 
 
 SAMPLE_DTYPE = np.dtype([("game_id", "<u8"), ("mask", "<u8"), ("value", "<u8"), ("policy", "<f4", (7,)),

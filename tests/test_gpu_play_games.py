@@ -194,3 +194,30 @@ def test_device_mode_tournament_matches_callback_mode_and_oracle():
         c4a0_amd.play_games(reqs, 64, 8, 1.4, 0.01, evaluator={3: dev_player(3)})
     with pytest.raises(TypeError):
         c4a0_amd.play_games(reqs, 64, 8, 1.4, 0.01, evaluator=dev_player(3))
+
+
+def test_concurrent_sessions_give_the_same_samples_as_one_session():
+    """play_games(concurrent_sessions=2): the resident games are split over two sessions replaying
+    their HIP graphs on separate streams (session.run_sessions).  Same samples, same order, as one
+    session; also with more games than slots (refill) and an odd split."""
+    import c4a0_amd
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 2, 2)), dev, dtype=torch.bfloat16)
+    reqs = [c4a0_amd.GameMetadata(100 + i, 0, 0) for i in range(37)]
+    st1, st2, st3 = {}, {}, {}
+    one = c4a0_amd.play_games(reqs, 64, 9, 6.6, 0.01, evaluator=net, resident_games=16, concurrent_sessions=1, stats=st1)
+    two = c4a0_amd.play_games(reqs, 64, 9, 6.6, 0.01, evaluator=net, resident_games=16, concurrent_sessions=2, stats=st2)
+    three = c4a0_amd.play_games(reqs, 64, 9, 6.6, 0.01, evaluator=net, resident_games=15, concurrent_sessions=3, stats=st3)
+    assert st1["concurrent_sessions"] == 1 and st2["concurrent_sessions"] == 2 and st3["concurrent_sessions"] == 3
+    assert st2["n_slots"] == 16 and st3["n_slots"] == 15
+    a = one.to_arrays()
+    for other, st in ((two, st2), (three, st3)):
+        b = other.to_arrays()
+        assert [r.metadata.game_id for r in other.results] == [r.game_id for r in reqs]
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        for k in ("sims", "moves", "games_done", "samples", "expansions", "backup_nodes"):
+            assert st[k] == st1[k], k

@@ -17,7 +17,7 @@ import torch
 os.environ.setdefault("C4A0_HIP_LIB", "libc4a0_hip_diag.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-NAMES = ["start->state loaded", "expand", "backup", "fence", "gate/move", "select", "encode+state store", "counters"]
+NAMES = ["start->state loaded", "expand", "backup", "fence", "gate/move", "select", "2nd trip + encode + state store", "counters"]
 
 
 def main():
@@ -69,6 +69,10 @@ def main():
         for name, a, b in seg:
             dt = (full[:, :, b] - full[:, :, a])[mv] / 100.0
             print(f"    {name:24s} median {np.median(dt):6.2f}  max {dt.max():6.2f}")
+    t2 = full[:, :, 13] > 0   # wavefronts in which some game ran a second simulation (terminal leaf)
+    if t2.any():
+        dt = (full[:, :, 13] - full[:, :, 6])[t2] / 100.0
+        print(f"  second trip (terminal leaf): {100.0 * t2.mean():.0f} % of wavefronts, median {np.median(dt):.2f}  p90 {np.percentile(dt, 90):.2f}  max {dt.max():.2f}")
     tot = (st[:, :, 8].max(axis=1) - st[:, :, 0].min(axis=1)) / 100.0
     print(f"  launch (first start -> last end): mean {tot.mean():.2f}")
     s.close()
