@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     // backed up here and now instead of idling through an evaluator pass.  The order of a game's
     // simulations and every value in them is unchanged; C4_FLAG_NO_MOVES / C4_FLAG_ONE_SIM_PER_STEP
     // keep exactly one.
-    const uint32_t max_sims = (p.flags & (C4_FLAG_NO_MOVES | C4_FLAG_ONE_SIM_PER_STEP)) ? 1u : 2u;
+    const uint32_t max_sims = (p.flags & (C4_FLAG_NO_MOVES | C4_FLAG_ONE_SIM_PER_STEP)) ? 1u : 2u;   // measured: 3 costs more launch time than it saves rows
 
     C4_STAMP(1, depth + n_blocks + leaf_ref + path_a + path_b + (uint32_t)leaf_mask);
 #define C4_STAMP_TRIP1(i, force) do { if (sim == 0) C4_STAMP(i, force); } while (0)
