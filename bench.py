@@ -4,9 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one lock-step MCTS simulation for every resident game: the ResNet evaluates the
-G leaf positions (HIP-graph replay, bf16) and the fused HIP step kernel consumes the outputs
-(expand, backup, move/finish/refill, select, encode the next leaves).  Workload at every N:
+One "step" = one lock-step MCTS round for every resident game: the ResNet evaluates the G leaf
+positions (HIP-graph replay, bf16) and the fused HIP step kernel consumes the outputs (expand,
+backup, move/finish/refill, select, encode the next leaves; a game whose new leaf is terminal
+runs that simulation in the same launch).  The G games are split over two sessions whose graphs
+replay concurrently on two streams (--sessions); a step advances both.  Workload at every N:
 BASELINE config 2 per GPU -- 4 096 concurrent games, n_mcts_iterations = 100, 4-block/32-channel
 ResNet in bf16, c_exploration 6.6, c_ply_penalty 0.01, game ids sharded id % N (weak scaling;
 config 3 is exactly this at N = 8).  Synthetic data: empty-board starts, random-init network
@@ -103,7 +105,8 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--steps", type=int, default=13500,
+                    help="timed lock-step rounds; the default completes >= 10 x 4096 games in the timed region (SURVEY 8d, C2)")
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--games-per-gpu", type=int, default=4096, help="resident games per GPU (BASELINE config 2: 4096)")
     ap.add_argument("--n-mcts", type=int, default=100)
