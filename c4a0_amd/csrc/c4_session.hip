@@ -2,7 +2,9 @@
 // behind the C ABI of include/c4a0_hip.h.
 //
 // Replaces the reference's CPU loop (rust/src/self_play.rs + mcts.rs + c4r.rs): G games stay
-// resident in HBM and advance in lock-step, one MCTS simulation per game per `c4_session_step`.
+// resident in HBM and advance in lock-step, one MCTS simulation per game per `c4_session_step`
+// (plus a second one in the same launch when the leaf just selected is terminal and so needs no
+// evaluator).
 //
 // Mapping to the hardware
 //   * one game  <-> one 8-lane group of a wave64 (lanes 0..6 = the 7 children of a node,
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
   }
 
   C4_STAMP(7, 0);
-  // ---------------- per-wavefront counters (one writer per row: no atomics) -----------------
+  // ---------------- per-wavefront counters (one row per wavefront: no contention) ----------
   // lane `sub` of each game adds that game's counter number `sub` to the wavefront's row: one
   // no-return atomic instruction for the whole wave (nobody waits for it; rows have one writer wave)
   {
