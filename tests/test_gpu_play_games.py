@@ -107,7 +107,11 @@ def test_tournament_style_multi_model_games():
     assert _as_oracle_dict(got) == oracle_samples_by_game(want)
 
 
-def test_device_mode_with_real_network_and_t3_replay_parity():
+@pytest.mark.parametrize("blocks,channels,n_iter", [
+    (1, 32, 12),    # small network, shallow search
+    (2, 64, 40),    # the 64-channel tower (BASELINE configs 4/5 family) and the F = 2688 head kernel, deeper trees
+])
+def test_device_mode_with_real_network_and_t3_replay_parity(blocks, channels, n_iter):
     """Device mode (leaves never leave HBM) with the bf16 ResNet, HIP-graph replayed.  T3 parity
     (SURVEY 8c): the run logs every (leaf position -> evaluator output) pair it consumed; the
     oracle replays the games with a lookup evaluator and must emit identical samples."""
@@ -119,9 +123,9 @@ def test_device_mode_with_real_network_and_t3_replay_parity():
 
     dev = torch.device("cuda:0")
     torch.manual_seed(1337)
-    net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 2, 2)), dev, dtype=torch.bfloat16)
+    net = InferenceNet(ConnectFourNet(ModelConfig(blocks, channels, 2, 2)), dev, dtype=torch.bfloat16)
     reqs = [(i, 0, 0) for i in range(24)]
-    s = DeviceSession(16, 12, 6.6, 0.01, device=dev, planes_dtype=torch.bfloat16)
+    s = DeviceSession(16, n_iter, 6.6, 0.01, device=dev, planes_dtype=torch.bfloat16)
     s.set_games(reqs)
     table = {}
 
@@ -155,11 +159,11 @@ def test_device_mode_with_real_network_and_t3_replay_parity():
         q = np.stack([np.frombuffer(a[1], dtype=np.float32) for a in ans])
         return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
 
-    want, _ = O.self_play(reqs, 64, 12, 6.6, 0.01, lookup)
+    want, _ = O.self_play(reqs, 64, n_iter, 6.6, 0.01, lookup)
     assert got == oracle_samples_by_game(want)
 
     # the same run through play_games(evaluator=...), HIP-graph replayed: identical samples again
-    res = c4a0_amd.play_games([c4a0_amd.GameMetadata(*r) for r in reqs], 64, 12, 6.6, 0.01, evaluator=net,
+    res = c4a0_amd.play_games([c4a0_amd.GameMetadata(*r) for r in reqs], 64, n_iter, 6.6, 0.01, evaluator=net,
                               resident_games=16, planes_dtype=torch.bfloat16)
     assert _as_oracle_dict(res) == oracle_samples_by_game(want)
 
