@@ -120,6 +120,10 @@ def main():
     ap.add_argument("--one-sim-per-step", action="store_true",
                     help="A/B knob: C4_FLAG_ONE_SIM_PER_STEP (no same-launch simulation for terminal leaves)")
     ap.add_argument("--instrumented-steps", type=int, default=300, help="event-bracketed launches for the roofline object")
+    ap.add_argument("--eval-cache", type=int, default=0,
+                    help="EXTENSION, off by default and NOT part of the headline: evaluation-cache entries per session "
+                         "(c4_session_set_eval_cache); repeated positions then skip the evaluator")
+    ap.add_argument("--eval-cache-sims", type=int, default=0, help="simulations per game per launch with the cache (0 = 4)")
     ap.add_argument("--sessions", type=int, default=2,
                     help="the resident games are split over this many sessions that replay their HIP graphs "
                          "concurrently on separate streams (1 = one session, one stream)")
@@ -155,7 +159,8 @@ def main():
     preroll = args.preroll if args.preroll >= 0 else int(2.0 * 15.0 * n_iter)  # ~2 game lengths of sims
     total_steps = preroll + args.warmup + args.steps + args.instrumented_steps + 64
     sims_per_game_lo = 8 * n_iter  # generous lower bound on sims per game -> upper bound on games needed
-    n_games = int(G * (2 + total_steps / sims_per_game_lo)) + G
+    trips = (args.eval_cache_sims or 4) if args.eval_cache else 1   # the cache lets a game run several simulations per step
+    n_games = int(G * (2 + trips * total_steps / sims_per_game_lo)) + G
     # ids sharded id % world == rank: rank r plays ids r, r+W, ...; on the GPU the resident
     # games are split over P sessions (c4a0_amd.session.run_sessions explains why), session p taking
     # every P-th of the rank's requests
@@ -166,6 +171,8 @@ def main():
         sp = DeviceSession((G + P - 1 - p) // P, n_iter, 6.6, 0.01, device=device, planes_dtype=torch.bfloat16,
                            one_sim_per_step=args.one_sim_per_step)
         sp.set_games([(i, 0, 0) for i in ids[p::P]])
+        if args.eval_cache:
+            sp.set_eval_cache(args.eval_cache, args.eval_cache_sims)
         st = torch.cuda.Stream(device=device) if P > 1 else torch.cuda.current_stream(device)
         with torch.cuda.stream(st):
             sp.bind(st)
@@ -303,10 +310,15 @@ def main():
                        "games_per_gpu": G, "n_mcts_iterations": n_iter, "parallelism": f"games sharded id%{world}",
                        "evaluator": "eager" if args.eager else f"hip-graph x{U} steps (evaluator + step kernel)",
                        "concurrent_sessions": P, "games_per_session": [sp.n_slots for sp in sessions], "preroll_steps": preroll,
+                       "eval_cache_entries_per_session": args.eval_cache,
                        "tree_dtype": "u64 bitboards + f32 UCT"},
             "sims_per_s": sims / elapsed_max,
             "ref_equivalent_sims_per_s": (sims + skipped) / elapsed_max,
             "games_completed": games,
+            "eval_cache": ({"probes": d["eval_cache_probes"], "hits": d["eval_cache_hits"],
+                            "hit_rate": d["eval_cache_hits"] / max(1, d["eval_cache_probes"]),
+                            "note": "EXTENSION switched on by --eval-cache: repeated positions skip the evaluator; not the headline configuration"}
+                           if args.eval_cache else None),
             "sims_per_game": sims / max(1.0, games),
             "roofline": {"bound": "hbm", "kernel": "c4_step_kernel (expand+backup+move+select+encode, fused)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

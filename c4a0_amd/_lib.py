@@ -44,7 +44,8 @@ class Config(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("sims", "select_levels", "backup_nodes", "expansions", "moves", "games_done",
-                                          "ref_skipped_sims", "samples", "games_started", "step_kernel_ns", "step_launches")] + \
+                                          "ref_skipped_sims", "samples", "games_started", "step_kernel_ns", "step_launches",
+                                          "eval_cache_probes", "eval_cache_hits")] + \
                [("error", C.c_uint32), ("error_slot", C.c_uint32)]
 
     def as_dict(self):
@@ -63,6 +64,7 @@ SIGNATURES = {
     "c4_session_bind_io": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "c4_session_set_dirichlet": (C.c_int, [_vp, C.c_float, C.c_float]),
     "c4_session_bind_leaf_models": (C.c_int, [_vp, _vp]),
+    "c4_session_set_eval_cache": (C.c_int, [_vp, C.c_uint64, C.c_uint32]),
     "c4_session_start": (C.c_int, [_vp]),
     "c4_session_step": (C.c_int, [_vp]),
     "c4_session_set_timing": (C.c_int, [_vp, C.c_int]),

@@ -124,7 +124,7 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
                evaluator: Optional[DeviceEvaluator] = None, device=None, resident_games: Optional[int] = None,
                planes_dtype: Optional[torch.dtype] = None, blocks_per_slot: int = 0,
                stats: Optional[dict] = None, dirichlet: Optional[tuple] = None,
-               concurrent_sessions: Optional[int] = None) -> PlayGamesResult:
+               concurrent_sessions: Optional[int] = None, eval_cache_entries: int = 0) -> PlayGamesResult:
     """Play every game of `reqs` to the end with MCTS self-play on the GPU and return the
     training samples (reference pybridge.rs:20-53).  Results are in `reqs` order (the
     reference's order is thread-finishing order, self_play.rs:116)."""
@@ -160,7 +160,7 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
     parts = max(1, min(parts, n_slots))
     if parts > 1:
         recs, counts = _play_concurrently(reqs, parts, n_slots, n_mcts_iterations, c_exploration, c_ply_penalty, evaluator,
-                                          device, planes_dtype, blocks_per_slot, dirichlet, stats)
+                                          device, planes_dtype, blocks_per_slot, dirichlet, stats, eval_cache_entries)
         return results_from_records(metas, recs, counts)
 
     sess = DeviceSession(n_slots, n_mcts_iterations, c_exploration, c_ply_penalty, device=device,
@@ -169,6 +169,10 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
         sess.set_games([(r.game_id, r.player0_id, r.player1_id) for r in reqs])
         if dirichlet is not None:   # extension: (alpha, epsilon) root noise; the reference has none
             sess.set_dirichlet(*dirichlet)
+        if eval_cache_entries:      # extension: evaluation cache, see DeviceSession.set_eval_cache
+            if multi:
+                raise TypeError("eval_cache_entries needs ONE evaluator (not evaluator={model_id: ...})")
+            sess.set_eval_cache(eval_cache_entries)
         if evaluator is None:
             p0 = np.array([r.player0_id for r in reqs], dtype=np.uint64)
             p1 = np.array([r.player1_id for r in reqs], dtype=np.uint64)
@@ -192,7 +196,7 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
 
 
 def _play_concurrently(reqs, parts, n_slots, n_mcts_iterations, c_exploration, c_ply_penalty, evaluator, device,
-                       planes_dtype, blocks_per_slot, dirichlet, stats):
+                       planes_dtype, blocks_per_slot, dirichlet, stats, eval_cache_entries=0):
     """Session p plays requests p, p + parts, ...; records and counts come back in request order."""
     from .session import SAMPLE_DTYPE, run_sessions
 
@@ -207,6 +211,8 @@ def _play_concurrently(reqs, parts, n_slots, n_mcts_iterations, c_exploration, c
             s.set_games([(r.game_id, r.player0_id, r.player1_id) for r in mine])
             if dirichlet is not None:
                 s.set_dirichlet(*dirichlet)
+            if eval_cache_entries:   # each session keeps its own table (half the entries each)
+                s.set_eval_cache(max(1024, int(eval_cache_entries) // parts))
         steps = run_sessions(sessions, evaluator, steps_per_graph=8)
         counts = np.zeros(len(reqs), dtype=np.uint32)
         part_counts = [s.sample_counts() for s in sessions]

@@ -101,7 +101,7 @@ enum : uint32_t { kIdle = 0, kActive = 1 };
 #define C4_STAMP(i, force) do { } while (0)
 #define C4_STAMP_ANY(i) do { } while (0)
 #endif
-enum : int { CTR_SIMS = 0, CTR_S, CTR_K, CTR_E, CTR_MOVES, CTR_DONE, CTR_SKIPPED, CTR_SAMPLES, CTR_N };
+enum : int { CTR_SIMS = 0, CTR_S, CTR_K, CTR_E, CTR_MOVES, CTR_DONE, CTR_SKIPPED, CTR_SAMPLES, CTR_PROBES, CTR_HITS, CTR_N = 16 };
 
 struct Globals {             // one small device struct of cross-wave words
   unsigned long long queue_head;   // next game ordinal to start
@@ -137,7 +137,23 @@ struct Params {
   float c_ply_penalty;
   uint32_t flags;
   float dir_alpha, dir_eps;       // Dirichlet root noise (extension); dir_eps == 0 disables
+  uint2* cache;                   // optional evaluation cache (extension): [cache_mask + 1] entries of 64 bytes, 8 x uint2
+  uint32_t cache_mask;
+  uint32_t max_sims;              // simulations one game may run in one launch (terminal / cached leaves need no evaluator)
 };
+
+// ------------------------------------------------------------------------------------------
+// Evaluation cache (extension, off by default): evaluator outputs keyed by position.
+// Entry = 16 dwords: [0..1] mask, [2..3] value, [4..10] the 7 policy outputs, [11..12] the 2 values,
+// [13] seal, [14..15] 0.  Lane `sub` of a game's group owns dwords 2 sub, 2 sub + 1, so an entry is
+// read and written by ONE 8-byte-per-lane instruction.  The seal makes the XOR of all 16 dwords a
+// constant: an empty (zeroed) or torn entry never validates.  Direct-mapped, always overwritten.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kCacheMagic = 0xC4A0C4A0u;
+C4_DEV uint32_t cache_index(uint64_t mask, uint64_t value, uint32_t cache_mask) {
+  const uint64_t h = (mask * 0x9E3779B97F4A7C15ull) ^ (value * 0xC2B2AE3D27D4EB4Full);
+  return (uint32_t)(h >> 24) & cache_mask;
+}
 
 // ------------------------------------------------------------------------------------------
 // 8-lane group helpers
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
   const uint32_t g = blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
 
   unsigned long long c_sims = 0, c_S = 0, c_K = 0, c_E = 0, c_moves = 0, c_done = 0, c_skipped = 0, c_samples = 0;
+  unsigned long long c_probes = 0, c_hits = 0;
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz device clock
   C4_STAMP(0, 0);
 #ifdef C4_PHASE_STAMPS
@@ -311,7 +328,12 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     // backed up here and now instead of idling through an evaluator pass.  The order of a game's
     // simulations and every value in them is unchanged; C4_FLAG_NO_MOVES / C4_FLAG_ONE_SIM_PER_STEP
     // keep exactly one.
-    const uint32_t max_sims = (p.flags & (C4_FLAG_NO_MOVES | C4_FLAG_ONE_SIM_PER_STEP)) ? 1u : 2u;   // measured: 3 costs more launch time than it saves rows
+    // (p.max_sims: 1 under those flags, else 2 -- measured: a third trip costs more launch time than
+    // it saves rows -- or more with the evaluation cache, whose hits need no evaluator either.)
+    const uint32_t max_sims = p.max_sims;
+    // this trip's evaluator outputs: the network's for the first trip, a cached entry's after a hit
+    float cur_logit = nn_logit;
+    float cur_qp = shfl_f32(nn_q, gbase), cur_qn = shfl_f32(nn_q, gbase + 1);
 
     C4_STAMP(1, depth + n_blocks + leaf_ref + path_a + path_b + (uint32_t)leaf_mask);
 #define C4_STAMP_TRIP1(i, force) do { if (sim == 0) C4_STAMP(i, force); } while (0)
@@ -327,7 +349,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
         const uint32_t legal = c4::legal_mask(leaf_mask);
         const bool is_legal = sub < 7 && ((legal >> sub) & 1u);
         float logit = __uint_as_float(0xff800000u);                             // mask_policy, c4r.rs:272-286
-        if (is_legal) logit = nn_logit;
+        if (is_legal) logit = cur_logit;
         float mx = logit;                                                       // f32::max fold (NaN-ignoring)
         mx = c4::rust_max(mx, grp_xchg<0>(mx));
         mx = c4::rust_max(mx, grp_xchg<1>(mx));
@@ -360,8 +382,24 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
           n_blocks = nb + 1;
           c_E += 1;
         }
-        v_pen = shfl_f32(nn_q, gbase);
-        v_nopen = shfl_f32(nn_q, gbase + 1);
+        v_pen = cur_qp;
+        v_nopen = cur_qn;
+        if (p.cache && sim == 0) {
+          // extension: remember what the evaluator said about this position (entry layout above)
+          const uint32_t lb = __float_as_uint(nn_logit);
+          const int s2 = 2 * ((int)sub - 2);
+          uint32_t a = shfl_u32(lb, gbase + (s2 < 0 ? 0 : (s2 > 6 ? 6 : s2)));
+          uint32_t b = shfl_u32(lb, gbase + (s2 + 1 < 0 ? 0 : (s2 + 1 > 6 ? 6 : s2 + 1)));
+          if (sub == 0) { a = (uint32_t)leaf_mask; b = (uint32_t)(leaf_mask >> 32); }
+          if (sub == 1) { a = (uint32_t)leaf_value; b = (uint32_t)(leaf_value >> 32); }
+          if (sub == 5) b = __float_as_uint(cur_qp);
+          if (sub == 6) { a = __float_as_uint(cur_qn); b = 0u; }
+          if (sub == 7) { a = 0u; b = 0u; }
+          uint32_t x = a ^ b;
+          x ^= grp_xchg<0>(x); x ^= grp_xchg<1>(x); x ^= grp_xchg<2>(x);
+          if (sub == 6) b = x ^ kCacheMagic;
+          p.cache[(size_t)cache_index(leaf_mask, leaf_value, p.cache_mask) * 8 + sub] = make_uint2(a, b);
+        }
       }
       if (err) break;
 
@@ -566,11 +604,33 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       if (err) break;
       leaf_mask = m; leaf_value = v; depth = d; leaf_ref = last_ref;
       C4_STAMP_TRIP1(6, d);
-      // a terminal leaf needs no evaluator: run its simulation now (second trip only)
       if (sim == 1) C4_STAMP_ANY(13);
-      if (sim + 1 < max_sims && c4::terminal_state(m, v)) {
-        if (depth >= 16) __threadfence_block();                // levels >= 16 are re-read from the slot's path
-        continue;
+      // a terminal leaf needs no evaluator, nor does one whose evaluation is in the cache: run that
+      // simulation now, while trips remain
+      if (sim + 1 < max_sims) {
+        bool again = c4::terminal_state(m, v) != 0;
+        if (!again && p.cache) {
+          const uint2 w = p.cache[(size_t)cache_index(m, v, p.cache_mask) * 8 + sub];
+          uint32_t x = w.x ^ w.y;
+          x ^= grp_xchg<0>(x); x ^= grp_xchg<1>(x); x ^= grp_xchg<2>(x);
+          const uint64_t key = ((uint64_t)w.y << 32) | w.x;
+          const bool kok = sub == 0 ? key == m : (sub == 1 ? key == v : true);
+          const bool hit = x == kCacheMagic && ((__ballot(kok) >> gbase) & 0xFFull) == 0xFFull;
+          c_probes += 1;
+          if (hit) {
+            c_hits += 1;
+            const int src = gbase + (int)((4 + sub) >> 1);          // dword 4 + sub lives in lane (4 + sub) / 2
+            const uint32_t ux = shfl_u32(w.x, src), uy = shfl_u32(w.y, src);
+            cur_logit = __uint_as_float(((4 + sub) & 1u) ? uy : ux);
+            cur_qp = __uint_as_float(shfl_u32(w.y, gbase + 5));
+            cur_qn = __uint_as_float(shfl_u32(w.x, gbase + 6));
+            again = true;
+          }
+        }
+        if (again) {
+          if (depth >= 16) __threadfence_block();              // levels >= 16 are re-read from the slot's path
+          continue;
+        }
       }
       break;
     }
@@ -611,6 +671,8 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     add = sub == CTR_SKIPPED ? c_skipped : add;
     add = sub == CTR_SAMPLES ? c_samples : add;
     if (add) atomicAdd(&p.wave_ctr[(size_t)blockIdx.x * CTR_N + sub], add);
+    const unsigned long long add2 = sub == 0 ? c_probes : (sub == 1 ? c_hits : 0ull);
+    if (add2) atomicAdd(&p.wave_ctr[(size_t)blockIdx.x * CTR_N + CTR_PROBES + sub], add2);
   }
   // ---------------- move RNG, off the critical path ------------------------------------------
   // The launch lasts as long as its slowest wavefront, and that is one with a MOVING game.  The
@@ -797,6 +859,7 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
   p.c_exploration = cfg->c_exploration;
   p.c_ply_penalty = cfg->c_ply_penalty;
   p.flags = cfg->flags;
+  p.max_sims = (cfg->flags & (C4_FLAG_NO_MOVES | C4_FLAG_ONE_SIM_PER_STEP)) ? 1u : 2u;
   hipError_t e;
   if ((e = hipMalloc(&p.slots, n * sizeof(Slot))) != hipSuccess ||
       (e = hipMalloc(&p.blocks, n * bps * sizeof(Block))) != hipSuccess ||
@@ -829,7 +892,7 @@ int c4_session_destroy(c4_session* s) {
   (void)hipSetDevice(s->cfg.device);
   if (s->stream) (void)hipStreamSynchronize(s->stream); else (void)hipDeviceSynchronize();
   (void)hipFree(s->p.slots); (void)hipFree(s->p.blocks); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob); (void)hipFree(s->p.stamps); (void)hipFree(s->p.clock_acc); (void)hipFree(s->p.phase);
-  (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts);
+  (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts); (void)hipFree(s->p.cache);
   (void)hipFree(s->reqs_dev); (void)hipFree(s->start_mask_dev); (void)hipFree(s->start_value_dev);
   if (s->probe_host) (void)hipHostFree(s->probe_host);
   if (s->probe_event) (void)hipEventDestroy(s->probe_event);
@@ -897,7 +960,29 @@ int c4_session_set_dirichlet(c4_session* s, float alpha, float epsilon) {
 
 int c4_session_bind_leaf_models(c4_session* s, uint64_t* leaf_models_dev) {
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  if (leaf_models_dev && s->p.cache) return fail(C4_ERR_BAD_ARG, "the evaluation cache holds ONE evaluator's outputs: not with multi-model games");
   s->p.leaf_models = leaf_models_dev;
+  return C4_OK;
+}
+
+int c4_session_set_eval_cache(c4_session* s, uint64_t n_entries, uint32_t max_sims_per_step) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  if (n_entries && s->p.leaf_models) return fail(C4_ERR_BAD_ARG, "the evaluation cache holds ONE evaluator's outputs: not with multi-model games");
+  if (n_entries > (1ull << 31)) return fail(C4_ERR_BAD_ARG, "at most 2^31 cache entries");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  (void)hipFree(s->p.cache);
+  s->p.cache = nullptr;
+  s->p.cache_mask = 0;
+  const bool single = (s->cfg.flags & (C4_FLAG_NO_MOVES | C4_FLAG_ONE_SIM_PER_STEP)) != 0;
+  s->p.max_sims = single ? 1u : 2u;
+  if (n_entries == 0) return C4_OK;
+  uint64_t n = 1024;
+  while (n < n_entries) n <<= 1;
+  HIP_TRY(hipMalloc(&s->p.cache, n * 64));
+  HIP_TRY(hipMemset(s->p.cache, 0, n * 64));   // an all-zero entry does not validate (its dwords XOR to 0, not to the seal constant)
+  s->p.cache_mask = (uint32_t)(n - 1);
+  if (!single) s->p.max_sims = max_sims_per_step ? (max_sims_per_step > 64 ? 64u : max_sims_per_step) : 4u;
   return C4_OK;
 }
 
@@ -959,6 +1044,7 @@ int c4_session_counters(c4_session* s, c4_counters* out) {
   out->sims = sum[CTR_SIMS]; out->select_levels = sum[CTR_S]; out->backup_nodes = sum[CTR_K];
   out->expansions = sum[CTR_E]; out->moves = sum[CTR_MOVES]; out->games_done = sum[CTR_DONE];
   out->ref_skipped_sims = sum[CTR_SKIPPED]; out->samples = sum[CTR_SAMPLES];
+  out->eval_cache_probes = sum[CTR_PROBES]; out->eval_cache_hits = sum[CTR_HITS];
   out->games_started = g.queue_head < s->n_games ? g.queue_head : s->n_games;
   out->error = g.error; out->error_slot = g.error_slot;
   // device-clock time of the step kernel: launches already folded in by the following launch,

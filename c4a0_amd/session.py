@@ -86,6 +86,13 @@ class DeviceSession:
         """Extension (not in the reference): Dirichlet noise on the priors of every search root."""
         check(self.L.c4_session_set_dirichlet(self._h, float(alpha), float(epsilon)))
 
+    def set_eval_cache(self, n_entries: int, max_sims_per_step: int = 0):
+        """Extension (not in the reference, off by default): keep the evaluator's outputs by position in a
+        direct-mapped table of `n_entries` x 64 bytes in HBM; a game whose new leaf is found there runs
+        that simulation in the same launch instead of using an evaluator row (c4_session_set_eval_cache).
+        Needs an evaluator that is a deterministic function of the position.  Call before start()."""
+        check(self.L.c4_session_set_eval_cache(self._h, int(n_entries), int(max_sims_per_step)))
+
     def bind_leaf_models(self) -> torch.Tensor:
         """int64[n_slots] tensor that start()/step() fill with the model id to evaluate each leaf with."""
         self.leaf_models = torch.zeros(self.n_slots, dtype=torch.int64, device=self.device)

@@ -94,6 +94,8 @@ typedef struct {
   uint64_t step_kernel_ns;  /* device-clock time inside c4_session_step's kernel, summed over launches:
                                last wavefront end - first wavefront start (s_memrealtime, 10 ns ticks) */
   uint64_t step_launches;   /* launches summed in step_kernel_ns */
+  uint64_t eval_cache_probes; /* leaves looked up in the evaluation cache (extension, c4_session_set_eval_cache) */
+  uint64_t eval_cache_hits;   /* ... and found: simulations that needed no evaluator row */
   uint32_t error;           /* first c4_status raised on the device, 0 = none */
   uint32_t error_slot;
 } c4_counters;
@@ -135,6 +137,16 @@ int c4_session_set_dirichlet(c4_session* s, float alpha, float epsilon);
  * (MctsGame::leaf_model_id_to_play, mcts.rs:70-76) to leaf_models_dev [n_slots] (uint64), so the
  * caller can route rows to evaluators without leaving the device.  NULL unbinds. */
 int c4_session_bind_leaf_models(c4_session* s, uint64_t* leaf_models_dev);
+
+/* Evaluation cache -- a BUILD EXTENSION, off by default (the reference evaluates every leaf and only
+ * dedups positions inside one batch, self_play.rs:203-208).  A direct-mapped table of n_entries
+ * (rounded up to a power of two, 64 bytes each) in HBM keeps the evaluator's raw outputs by position;
+ * a game whose freshly selected leaf is found there runs that simulation in the same launch, like a
+ * terminal leaf, up to max_sims_per_step simulations per game per c4_session_step (0 = 4).  Samples
+ * are unchanged provided the evaluator is a deterministic function of the position (a network in
+ * inference mode is); one evaluator per session, so not together with c4_session_bind_leaf_models.
+ * n_entries = 0 frees the table.  Call before c4_session_start / graph capture.  Synchronises. */
+int c4_session_set_eval_cache(c4_session* s, uint64_t n_entries, uint32_t max_sims_per_step);
 
 /* Puts the first n_slots games on the slots and writes their first leaf (the start position)
  * to planes_dev: the state self_play() is in after self_play.rs:55-58. */

@@ -283,3 +283,56 @@ def test_dirichlet_noise_extension_matches_its_specification(env):
         want, _ = O.self_play(reqs, 64, 20, 6.6, 0.01, "hash", dirichlet=noise)
         assert results[name] == oracle_samples_by_game(want), name
         assert results[name] != results["off"]
+
+
+@pytest.mark.parametrize("entries,max_sims", [(1 << 16, 0), (1024, 8)])   # roomy table; tiny table (constant eviction), long trips
+def test_evaluation_cache_extension_keeps_every_sample(env, entries, max_sims):
+    """c4_session_set_eval_cache (extension, off by default): positions whose evaluation is already
+    in the table run their simulation without an evaluator row.  Under a deterministic evaluator
+    nothing a game records may change: samples and the per-game work counters equal the oracle's,
+    while the evaluator sees fewer rows."""
+    DeviceSession, O, dev = env
+    from tests.helpers import hash_eval_torch, oracle_samples_by_game, samples_by_game
+
+    reqs = [(gid, 0, 0) for gid in [0, 42, 43] + list(range(2000, 2045))]
+    n_iter = 30
+    evaluated = []
+
+    def counting_eval(planes):
+        evaluated.append(planes.shape[0])
+        return hash_eval_torch(planes)
+
+    out = {}
+    for name, use_cache in (("off", False), ("on", True)):
+        s = DeviceSession(16, n_iter, 6.6, 0.01, device=dev)
+        s.set_games(reqs)
+        if use_cache:
+            s.set_eval_cache(entries, max_sims)
+        steps = s.run(counting_eval)
+        out[name] = (samples_by_game(s.drain_samples()), s.counters(), steps)
+        s.close()
+    ores, ost = O.self_play(reqs, 1 << 20, n_iter, 6.6, 0.01, "hash")
+    want = oracle_samples_by_game(ores)
+    (got_off, c_off, steps_off), (got_on, c_on, steps_on) = out["off"], out["on"]
+    assert got_off == want and got_on == want
+    for k in ("sims", "select_levels", "backup_nodes", "expansions", "moves", "games_done", "samples", "ref_skipped_sims"):
+        assert c_on[k] == c_off[k], k
+    assert c_off["eval_cache_probes"] == 0 and c_off["eval_cache_hits"] == 0
+    assert 0 < c_on["eval_cache_hits"] <= c_on["eval_cache_probes"]
+    assert steps_on < steps_off          # the same simulations in fewer evaluator passes
+
+
+def test_evaluation_cache_is_refused_for_multi_model_sessions(env):
+    DeviceSession, O, dev = env
+    from c4a0_amd._lib import C4Error
+
+    s = DeviceSession(8, 10, 6.6, 0.01, device=dev)
+    s.bind_leaf_models()
+    with pytest.raises(C4Error):
+        s.set_eval_cache(4096)
+    s.close()
+    s = DeviceSession(8, 10, 6.6, 0.01, device=dev)
+    s.set_eval_cache(4096)
+    with pytest.raises(C4Error):
+        s.bind_leaf_models()
+    s.close()

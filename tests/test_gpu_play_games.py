@@ -225,3 +225,28 @@ def test_concurrent_sessions_give_the_same_samples_as_one_session():
             assert np.array_equal(x, y)
         for k in ("sims", "moves", "games_done", "samples", "expansions", "backup_nodes"):
             assert st[k] == st1[k], k
+
+
+def test_evaluation_cache_with_the_real_network_changes_no_sample():
+    """play_games(eval_cache_entries=...) with the bf16 network, one and two concurrent sessions: the
+    cached outputs are the network's own earlier answers for the same position, so every sample
+    equals the run without the cache, and the evaluator passes drop."""
+    import c4a0_amd
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 2, 2)), dev, dtype=torch.bfloat16)
+    reqs = [c4a0_amd.GameMetadata(500 + i, 0, 0) for i in range(48)]
+    st0, st1, st2 = {}, {}, {}
+    base = c4a0_amd.play_games(reqs, 64, 25, 6.6, 0.01, evaluator=net, resident_games=32, concurrent_sessions=1, stats=st0)
+    one = c4a0_amd.play_games(reqs, 64, 25, 6.6, 0.01, evaluator=net, resident_games=32, concurrent_sessions=1,
+                              eval_cache_entries=1 << 16, stats=st1)
+    two = c4a0_amd.play_games(reqs, 64, 25, 6.6, 0.01, evaluator=net, resident_games=32, concurrent_sessions=2,
+                              eval_cache_entries=1 << 16, stats=st2)
+    a = base.to_arrays()
+    for other in (one, two):
+        for x, y in zip(a, other.to_arrays()):
+            assert np.array_equal(x, y)
+    assert st0["eval_cache_hits"] == 0 and st1["eval_cache_hits"] > 0 and st2["eval_cache_hits"] > 0
+    assert st1["sims"] == st0["sims"] == st2["sims"] and st1["steps"] < st0["steps"]
