@@ -140,13 +140,6 @@ def main():
         sys.exit("bench.py needs a HIP device")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or os.environ.get("C4_BENCH_FORCE_DIST") == "1":  # the env knob exercises the RCCL path at world size 1
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")   # only reached without a launcher (the world-size-1 knob above)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
     from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig, flops_per_leaf
     from c4a0_amd.session import DeviceSession
 
@@ -185,6 +178,15 @@ def main():
             graphs.append(sp.capture_steps(net, U, stream=st if P > 1 else None))
         sessions.append(sp)
         streams.append(st)
+
+    # RCCL comes up only now, AFTER the HIP graphs are captured: its watchdog thread must not poll
+    # events while a stream capture is open
+    dist = None
+    if world > 1 or os.environ.get("C4_BENCH_FORCE_DIST") == "1":  # the env knob exercises the RCCL path at world size 1
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")   # only reached without a launcher (the world-size-1 knob above)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     def counters():
         tot = {}
