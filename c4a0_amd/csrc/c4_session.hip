@@ -935,6 +935,8 @@ int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n
   s->have_games = true;
   HIP_TRY(hipMemset(s->p.stamps, 0, (size_t)s->n_waves * 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(s->p.clock_acc, 0, 2 * sizeof(unsigned long long)));
+  // a new list of games may come with new evaluator weights: forget the old evaluations
+  if (s->p.cache) HIP_TRY(hipMemset(s->p.cache, 0, ((size_t)s->p.cache_mask + 1) * 64));
   s->seq = 0;
   s->probe_pending = false; s->probe_done = 0; s->probe_error = 0;
   return C4_OK;

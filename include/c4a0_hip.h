@@ -145,7 +145,8 @@ int c4_session_bind_leaf_models(c4_session* s, uint64_t* leaf_models_dev);
  * terminal leaf, up to max_sims_per_step simulations per game per c4_session_step (0 = 4).  Samples
  * are unchanged provided the evaluator is a deterministic function of the position (a network in
  * inference mode is); one evaluator per session, so not together with c4_session_bind_leaf_models.
- * n_entries = 0 frees the table.  Call before c4_session_start / graph capture.  Synchronises. */
+ * n_entries = 0 frees the table; c4_session_set_games empties it (new games may come with new weights).
+ * Call before c4_session_start / graph capture.  Synchronises. */
 int c4_session_set_eval_cache(c4_session* s, uint64_t n_entries, uint32_t max_sims_per_step);
 
 /* Puts the first n_slots games on the slots and writes their first leaf (the start position)
