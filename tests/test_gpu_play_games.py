@@ -250,3 +250,29 @@ def test_evaluation_cache_with_the_real_network_changes_no_sample():
             assert np.array_equal(x, y)
     assert st0["eval_cache_hits"] == 0 and st1["eval_cache_hits"] > 0 and st2["eval_cache_hits"] > 0
     assert st1["sims"] == st0["sims"] == st2["sims"] and st1["steps"] < st0["steps"]
+
+
+def test_device_resident_training_tensors_equal_the_reference_conversion():
+    """finished samples -> training tensors without leaving HBM
+    (c4a0_amd.dataset).  Must equal `Sample.to_numpy()` (types.rs:125-147) of every sample followed,
+    like the reference's SampleDataModule (training.py:317), by every sample's `flip_h()`."""
+    from c4a0_amd import GameMetadata
+    from c4a0_amd.dataset import training_tensors
+    from c4a0_amd.results import results_from_records
+    from c4a0_amd.session import DeviceSession
+    from tests.helpers import hash_eval_torch
+
+    dev = torch.device("cuda:0")
+    reqs = [(700 + i, 0, 0) for i in range(20)]
+    s = DeviceSession(8, 12, 6.6, 0.01, device=dev)
+    s.set_games(reqs)
+    s.run(hash_eval_torch)
+    pos, policy, qp, qn = (t.cpu().numpy() for t in training_tensors(s))
+    res = results_from_records([GameMetadata(*r) for r in reqs], s.drain_samples(), s.sample_counts())
+    s.close()
+    samples = [smp for r in res.results for smp in r.samples]
+    samples = samples + [smp.flip_h() for smp in samples]
+    assert pos.shape == (len(samples), 2, 6, 7) and policy.shape == (len(samples), 7)
+    for i, smp in enumerate(samples):
+        a, b, c, d = smp.to_numpy()
+        assert np.array_equal(pos[i], a) and np.array_equal(policy[i], b) and qp[i] == c and qn[i] == d
