@@ -8,7 +8,7 @@ def bench(fn, n=200):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b)/n*1e3
-M=4096
+M=int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 for K,N in ((1344,1344),(1344,2688),(2688,2688),(2688,5376)):
     x=torch.randn(M,K,device=dev,dtype=torch.bfloat16); w=torch.randn(N,K,device=dev,dtype=torch.bfloat16); b=torch.randn(N,device=dev,dtype=torch.bfloat16)
     t1=bench(lambda: torch.nn.functional.linear(x,w,b))
