@@ -184,6 +184,112 @@ C4_DEV uint32_t child_link(const uint4& raw, uint32_t col, int gbase) {
   return (shfl_u32(mine, gbase + 7) >> (16u * (col & 1u))) & 0xFFFFu;
 }
 
+// Evaluation cache, lane-group side (entry layout at kCacheMagic).  `logit` = policy output `sub` on
+// lanes 0..6; q_pen / q_nopen group-uniform.
+C4_DEV void cache_store(uint2* cache, uint32_t cache_mask, uint64_t mask, uint64_t value, float logit, float q_pen,
+                        float q_nopen, uint32_t sub, int gbase) {
+  const uint32_t lb = __float_as_uint(logit);
+  const int s2 = 2 * ((int)sub - 2);
+  uint32_t a = shfl_u32(lb, gbase + (s2 < 0 ? 0 : (s2 > 6 ? 6 : s2)));
+  uint32_t b = shfl_u32(lb, gbase + (s2 + 1 < 0 ? 0 : (s2 + 1 > 6 ? 6 : s2 + 1)));
+  if (sub == 0) { a = (uint32_t)mask; b = (uint32_t)(mask >> 32); }
+  if (sub == 1) { a = (uint32_t)value; b = (uint32_t)(value >> 32); }
+  if (sub == 5) b = __float_as_uint(q_pen);
+  if (sub == 6) { a = __float_as_uint(q_nopen); b = 0u; }
+  if (sub == 7) { a = 0u; b = 0u; }
+  uint32_t x = a ^ b;
+  x ^= grp_xchg<0>(x); x ^= grp_xchg<1>(x); x ^= grp_xchg<2>(x);
+  if (sub == 6) b = x ^ kCacheMagic;                               // the 16 dwords now XOR to the constant
+  cache[(size_t)cache_index(mask, value, cache_mask) * 8 + sub] = make_uint2(a, b);
+}
+// true (for the whole group) when a valid entry for (mask, value) is present; then the outputs are set
+C4_DEV bool cache_lookup(const uint2* cache, uint32_t cache_mask, uint64_t mask, uint64_t value, float& logit, float& q_pen,
+                         float& q_nopen, uint32_t sub, int gbase) {
+  const uint2 w = cache[(size_t)cache_index(mask, value, cache_mask) * 8 + sub];
+  uint32_t x = w.x ^ w.y;
+  x ^= grp_xchg<0>(x); x ^= grp_xchg<1>(x); x ^= grp_xchg<2>(x);
+  const uint64_t key = ((uint64_t)w.y << 32) | w.x;
+  const bool kok = sub == 0 ? key == mask : (sub == 1 ? key == value : true);
+  const bool hit = x == kCacheMagic && ((__ballot(kok) >> gbase) & 0xFFull) == 0xFFull;
+  if (hit) {
+    const int src = gbase + (int)((4 + sub) >> 1);                   // dword 4 + sub lives in lane (4 + sub) / 2
+    const uint32_t ux = shfl_u32(w.x, src), uy = shfl_u32(w.y, src);
+    logit = __uint_as_float(((4 + sub) & 1u) ? uy : ux);
+    q_pen = __uint_as_float(shfl_u32(w.y, gbase + 5));
+    q_nopen = __uint_as_float(shfl_u32(w.x, gbase + 6));
+  }
+  return hit;
+}
+
+// select_new_leaf (mcts.rs:160-183) for one game on its 8 lanes: from the root down to the first
+// unexpanded node, replaying make_move, recording the path (entry refs) in the slot and -- for the
+// backup of a same-launch simulation -- in the lanes (lane `sub` keeps levels sub and sub + 8).
+// Returns 0 or C4_ERR_NAN_IN_TREE.
+C4_DEV uint32_t select_leaf(const Block* blocks, Slot* st, uint64_t rmask, uint64_t rvalue, uint32_t root_block,
+                            uint32_t root_ref, uint32_t root_n, float c_exploration, uint32_t sub, int gbase,
+                            uint64_t& leaf_mask, uint64_t& leaf_value, uint32_t& depth, uint32_t& leaf_ref,
+                            uint32_t& path_a, uint32_t& path_b, unsigned long long& levels) {
+  uint64_t m = rmask, v = rvalue;
+  uint32_t blk = root_block, d = 0, last_ref = root_ref;
+  float ln_np = c4::c4_logf((float)root_n);               // ln(parent visits) of the level being scored
+  path_a = (sub == 0) ? root_ref : path_a;                // level 0 of the path = the root's own entry
+  while (blk != 0 && d + 1 < kMaxPath) {
+    const uint4 ce = load_block_lane(blocks, blk, sub);   // {n, q_pen, q_nopen, prior} | tail
+    // Off the dependent chain: every lane fetches ITS child's link out of the tail (lane 7) and
+    // takes ln of ITS child's visit count -- the parent term of the next level if that child wins.
+    const uint32_t t0 = shfl_u32(ce.x, gbase + 7), t1 = shfl_u32(ce.y, gbase + 7);
+    const uint32_t t2 = shfl_u32(ce.z, gbase + 7), t3 = shfl_u32(ce.w, gbase + 7);
+    const uint32_t tw = (sub >> 1) == 0 ? t0 : ((sub >> 1) == 1 ? t1 : ((sub >> 1) == 2 ? t2 : t3));
+    const uint32_t my_link = (tw >> (16u * (sub & 1u))) & 0xFFFFu;
+    const float my_ln = c4::c4_logf((float)ce.x);
+    const uint32_t legal = c4::legal_mask(m);
+    const bool ok = sub < 7 && ((legal >> sub) & 1u);
+    float score = 0.0f;
+    if (ok) {
+      // uct_value (mcts.rs:359-388); c4_logf(1) == 0 makes every first-level score -0+0
+      const float nf = (float)ce.x + 1.0f;
+      const float qv = __uint_as_float(ce.y) / nf;
+      float ex = ln_np / nf;
+      ex = __builtin_sqrtf(ex);
+      ex = ex * (__uint_as_float(ce.w) + 1e-8f);
+      const float cx = c_exploration * ex;
+      score = -qv + cx;
+    }
+    // max_by_key keeps the LAST maximum (mcts.rs:165-173); NaN panics (utils.rs:12)
+    const bool isn = ok && (score != score);
+    const unsigned long long nan_ballot = __ballot(isn) >> gbase & 0xFFull;
+    if (nan_ballot && __popc(legal) >= 2) return C4_ERR_NAN_IN_TREE;
+    // argmax over the group; the winner's visit count, link and ln travel with it
+    float bs = score, bln = my_ln;
+    int bi = ok ? (int)sub : -1;
+    uint32_t bn = ce.x, bl = my_link;
+#define C4_ARGMAX_STEP(K)                                                                        \
+    {                                                                                        \
+      const float os = grp_xchg<K>(bs), oln = grp_xchg<K>(bln);                              \
+      const int oi = (int)grp_xchg<K>((uint32_t)bi);                                         \
+      const uint32_t on = grp_xchg<K>(bn), ol = grp_xchg<K>(bl);                             \
+      const bool take = (oi >= 0) && (bi < 0 || os > bs || (os == bs && oi > bi));           \
+      bs = take ? os : bs; bi = take ? oi : bi; bn = take ? on : bn;                         \
+      bl = take ? ol : bl; bln = take ? oln : bln;                                           \
+    }
+    C4_ARGMAX_STEP(0) C4_ARGMAX_STEP(1) C4_ARGMAX_STEP(2)
+#undef C4_ARGMAX_STEP
+    const uint32_t best = (uint32_t)bi;
+    ln_np = bln;
+    const uint32_t next_blk = bl;
+    c4::make_move(m, v, best);
+    d += 1;
+    last_ref = (blk << 3) | best;
+    if (sub == 0) st->path[d] = last_ref;
+    path_a = (d == sub) ? last_ref : path_a;               // the lanes keep their own backup levels
+    path_b = (d == sub + 8) ? last_ref : path_b;
+    blk = next_blk;
+    levels += 1;
+  }
+  leaf_mask = m; leaf_value = v; depth = d; leaf_ref = last_ref;
+  return 0;
+}
+
 C4_DEV void raise_error(const Params& p, Slot* st, uint32_t g, uint32_t code) {
   st->status = code;
   if (atomicCAS(&p.glob->error, 0u, code) == 0u) p.glob->error_slot = g;
@@ -258,7 +364,7 @@ __global__ __launch_bounds__(64) void c4_start_kernel(Params p) {
 //   -> gate / move / finish / refill (self_play.rs:283-308, mcts.rs:187-222, 271-313)
 //   -> select (mcts.rs:160-183)  ->  encode the new leaf (c4r.rs:378-392)
 // ------------------------------------------------------------------------------------------
-template <typename PlaneT, bool NOISE>
+template <typename PlaneT, bool NOISE, bool CACHE>
 __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t sub = lane & 7;
@@ -384,22 +490,8 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
         }
         v_pen = cur_qp;
         v_nopen = cur_qn;
-        if (p.cache && sim == 0) {
-          // extension: remember what the evaluator said about this position (entry layout above)
-          const uint32_t lb = __float_as_uint(nn_logit);
-          const int s2 = 2 * ((int)sub - 2);
-          uint32_t a = shfl_u32(lb, gbase + (s2 < 0 ? 0 : (s2 > 6 ? 6 : s2)));
-          uint32_t b = shfl_u32(lb, gbase + (s2 + 1 < 0 ? 0 : (s2 + 1 > 6 ? 6 : s2 + 1)));
-          if (sub == 0) { a = (uint32_t)leaf_mask; b = (uint32_t)(leaf_mask >> 32); }
-          if (sub == 1) { a = (uint32_t)leaf_value; b = (uint32_t)(leaf_value >> 32); }
-          if (sub == 5) b = __float_as_uint(cur_qp);
-          if (sub == 6) { a = __float_as_uint(cur_qn); b = 0u; }
-          if (sub == 7) { a = 0u; b = 0u; }
-          uint32_t x = a ^ b;
-          x ^= grp_xchg<0>(x); x ^= grp_xchg<1>(x); x ^= grp_xchg<2>(x);
-          if (sub == 6) b = x ^ kCacheMagic;
-          p.cache[(size_t)cache_index(leaf_mask, leaf_value, p.cache_mask) * 8 + sub] = make_uint2(a, b);
-        }
+        if (CACHE && sim == 0)     // extension: remember what the evaluator said about this position
+          cache_store(p.cache, p.cache_mask, leaf_mask, leaf_value, nn_logit, cur_qp, cur_qn, sub, gbase);
       }
       if (err) break;
 
@@ -544,88 +636,19 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       }
       C4_STAMP_TRIP1(5, root_n);
       // ---------------- select_new_leaf (mcts.rs:160-183) -------------------------------
-      uint64_t m = rmask, v = rvalue;
-      uint32_t blk = root_block, d = 0, last_ref = root_ref;
-      float ln_np = c4::c4_logf((float)root_n);               // ln(parent visits) of the level being scored
-      path_a = (sub == 0) ? root_ref : path_a;                // level 0 of the path = the root's own entry
-      while (blk != 0 && d + 1 < kMaxPath) {
-        const uint4 ce = load_block_lane(blocks, blk, sub);   // {n, q_pen, q_nopen, prior} | tail
-        // Off the dependent chain: every lane fetches ITS child's link out of the tail (lane 7) and
-        // takes ln of ITS child's visit count -- the parent term of the next level if that child wins.
-        const uint32_t t0 = shfl_u32(ce.x, gbase + 7), t1 = shfl_u32(ce.y, gbase + 7);
-        const uint32_t t2 = shfl_u32(ce.z, gbase + 7), t3 = shfl_u32(ce.w, gbase + 7);
-        const uint32_t tw = (sub >> 1) == 0 ? t0 : ((sub >> 1) == 1 ? t1 : ((sub >> 1) == 2 ? t2 : t3));
-        const uint32_t my_link = (tw >> (16u * (sub & 1u))) & 0xFFFFu;
-        const float my_ln = c4::c4_logf((float)ce.x);
-        const uint32_t legal = c4::legal_mask(m);
-        const bool ok = sub < 7 && ((legal >> sub) & 1u);
-        float score = 0.0f;
-        if (ok) {
-          // uct_value (mcts.rs:359-388); c4_logf(1) == 0 makes every first-level score -0+0
-          const float nf = (float)ce.x + 1.0f;
-          const float qv = __uint_as_float(ce.y) / nf;
-          float ex = ln_np / nf;
-          ex = __builtin_sqrtf(ex);
-          ex = ex * (__uint_as_float(ce.w) + 1e-8f);
-          const float cx = p.c_exploration * ex;
-          score = -qv + cx;
-        }
-        // max_by_key keeps the LAST maximum (mcts.rs:165-173); NaN panics (utils.rs:12)
-        const bool isn = ok && (score != score);
-        const unsigned long long nan_ballot = __ballot(isn) >> gbase & 0xFFull;
-        if (nan_ballot && __popc(legal) >= 2) { err = C4_ERR_NAN_IN_TREE; break; }
-        // argmax over the group; the winner's visit count, link and ln travel with it
-        float bs = score, bln = my_ln;
-        int bi = ok ? (int)sub : -1;
-        uint32_t bn = ce.x, bl = my_link;
-#define C4_ARGMAX_STEP(K)                                                                        \
-        {                                                                                        \
-          const float os = grp_xchg<K>(bs), oln = grp_xchg<K>(bln);                              \
-          const int oi = (int)grp_xchg<K>((uint32_t)bi);                                         \
-          const uint32_t on = grp_xchg<K>(bn), ol = grp_xchg<K>(bl);                             \
-          const bool take = (oi >= 0) && (bi < 0 || os > bs || (os == bs && oi > bi));           \
-          bs = take ? os : bs; bi = take ? oi : bi; bn = take ? on : bn;                         \
-          bl = take ? ol : bl; bln = take ? oln : bln;                                           \
-        }
-        C4_ARGMAX_STEP(0) C4_ARGMAX_STEP(1) C4_ARGMAX_STEP(2)
-#undef C4_ARGMAX_STEP
-        const uint32_t best = (uint32_t)bi;
-        ln_np = bln;
-        const uint32_t next_blk = bl;
-        c4::make_move(m, v, best);
-        d += 1;
-        last_ref = (blk << 3) | best;
-        if (sub == 0) st->path[d] = last_ref;
-        path_a = (d == sub) ? last_ref : path_a;               // the lanes keep their own backup levels
-        path_b = (d == sub + 8) ? last_ref : path_b;
-        blk = next_blk;
-        c_S += 1;
-      }
+      err = select_leaf(blocks, st, rmask, rvalue, root_block, root_ref, root_n, p.c_exploration, sub, gbase,
+                        leaf_mask, leaf_value, depth, leaf_ref, path_a, path_b, c_S);
       if (err) break;
-      leaf_mask = m; leaf_value = v; depth = d; leaf_ref = last_ref;
-      C4_STAMP_TRIP1(6, d);
+      C4_STAMP_TRIP1(6, depth);
       if (sim == 1) C4_STAMP_ANY(13);
       // a terminal leaf needs no evaluator, nor does one whose evaluation is in the cache: run that
       // simulation now, while trips remain
       if (sim + 1 < max_sims) {
-        bool again = c4::terminal_state(m, v) != 0;
-        if (!again && p.cache) {
-          const uint2 w = p.cache[(size_t)cache_index(m, v, p.cache_mask) * 8 + sub];
-          uint32_t x = w.x ^ w.y;
-          x ^= grp_xchg<0>(x); x ^= grp_xchg<1>(x); x ^= grp_xchg<2>(x);
-          const uint64_t key = ((uint64_t)w.y << 32) | w.x;
-          const bool kok = sub == 0 ? key == m : (sub == 1 ? key == v : true);
-          const bool hit = x == kCacheMagic && ((__ballot(kok) >> gbase) & 0xFFull) == 0xFFull;
+        bool again = c4::terminal_state(leaf_mask, leaf_value) != 0;
+        if (CACHE && !again) {
           c_probes += 1;
-          if (hit) {
-            c_hits += 1;
-            const int src = gbase + (int)((4 + sub) >> 1);          // dword 4 + sub lives in lane (4 + sub) / 2
-            const uint32_t ux = shfl_u32(w.x, src), uy = shfl_u32(w.y, src);
-            cur_logit = __uint_as_float(((4 + sub) & 1u) ? uy : ux);
-            cur_qp = __uint_as_float(shfl_u32(w.y, gbase + 5));
-            cur_qn = __uint_as_float(shfl_u32(w.x, gbase + 6));
-            again = true;
-          }
+          again = cache_lookup(p.cache, p.cache_mask, leaf_mask, leaf_value, cur_logit, cur_qp, cur_qn, sub, gbase);
+          c_hits += again ? 1 : 0;
         }
         if (again) {
           if (depth >= 16) __threadfence_block();              // levels >= 16 are re-read from the slot's path
@@ -1006,15 +1029,16 @@ int c4_session_step(c4_session* s) {
   // launch sequence number for the device-clock stamps; frozen at 0 (= no per-launch timing) when
   // timing is off, which is what a launch captured into a HIP graph needs (arguments are baked in)
   s->p.seq = s->timing ? ++s->seq : 0;
-  // the Dirichlet-noise extension is a separate instantiation: the default kernel carries none of its
-  // registers or scratch
-  const bool noise = s->p.dir_eps > 0.0f;
+  // the Dirichlet-noise and evaluation-cache extensions are separate instantiations: the default
+  // kernel carries none of their registers or scratch
+  const bool noise = s->p.dir_eps > 0.0f, cache = s->p.cache != nullptr;
+  auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(s->n_waves), dim3(64), 0, s->stream, s->p); };
   if (s->cfg.planes_dtype == 0) {
-    if (noise) hipLaunchKernelGGL((c4_step_kernel<float, true>), dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
-    else hipLaunchKernelGGL((c4_step_kernel<float, false>), dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+    if (noise) { if (cache) launch(c4_step_kernel<float, true, true>); else launch(c4_step_kernel<float, true, false>); }
+    else       { if (cache) launch(c4_step_kernel<float, false, true>); else launch(c4_step_kernel<float, false, false>); }
   } else {
-    if (noise) hipLaunchKernelGGL((c4_step_kernel<uint16_t, true>), dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
-    else hipLaunchKernelGGL((c4_step_kernel<uint16_t, false>), dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+    if (noise) { if (cache) launch(c4_step_kernel<uint16_t, true, true>); else launch(c4_step_kernel<uint16_t, true, false>); }
+    else       { if (cache) launch(c4_step_kernel<uint16_t, false, true>); else launch(c4_step_kernel<uint16_t, false, false>); }
   }
   HIP_TRY(hipGetLastError());
   return C4_OK;
