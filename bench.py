@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--eval-cache", type=int, default=0,
                     help="EXTENSION, off by default and NOT part of the headline: evaluation-cache entries per session "
                          "(c4_session_set_eval_cache); repeated positions then skip the evaluator")
-    ap.add_argument("--eval-cache-sims", type=int, default=0, help="simulations per game per launch with the cache (0 = 4)")
+    ap.add_argument("--eval-cache-sims", type=int, default=0, help="simulations per game per launch with the cache (0 = 6)")
     ap.add_argument("--sessions", type=int, default=2,
                     help="the resident games are split over this many sessions that replay their HIP graphs "
                          "concurrently on separate streams (1 = one session, one stream)")
@@ -152,7 +152,7 @@ def main():
     preroll = args.preroll if args.preroll >= 0 else int(2.0 * 15.0 * n_iter)  # ~2 game lengths of sims
     total_steps = preroll + args.warmup + args.steps + args.instrumented_steps + 64
     sims_per_game_lo = 8 * n_iter  # generous lower bound on sims per game -> upper bound on games needed
-    trips = (args.eval_cache_sims or 4) if args.eval_cache else 1   # the cache lets a game run several simulations per step
+    trips = (args.eval_cache_sims or 6) if args.eval_cache else 1   # the cache lets a game run several simulations per step
     n_games = int(G * (2 + trips * total_steps / sims_per_game_lo)) + G
     # ids sharded id % world == rank: rank r plays ids r, r+W, ...; on the GPU the resident
     # games are split over P sessions (c4a0_amd.session.run_sessions explains why), session p taking

@@ -142,7 +142,7 @@ int c4_session_bind_leaf_models(c4_session* s, uint64_t* leaf_models_dev);
  * dedups positions inside one batch, self_play.rs:203-208).  A direct-mapped table of n_entries
  * (rounded up to a power of two, 64 bytes each) in HBM keeps the evaluator's raw outputs by position;
  * a game whose freshly selected leaf is found there runs that simulation in the same launch, like a
- * terminal leaf, up to max_sims_per_step simulations per game per c4_session_step (0 = 4).  Samples
+ * terminal leaf, up to max_sims_per_step simulations per game per c4_session_step (0 = 6).  Samples
  * are unchanged provided the evaluator is a deterministic function of the position (a network in
  * inference mode is); one evaluator per session, so not together with c4_session_bind_leaf_models.
  * n_entries = 0 frees the table; c4_session_set_games empties it (new games may come with new weights).
