@@ -283,6 +283,17 @@ def test_dirichlet_noise_extension_matches_its_specification(env):
         want, _ = O.self_play(reqs, 64, 20, 6.6, 0.01, "hash", dirichlet=noise)
         assert results[name] == oracle_samples_by_game(want), name
         assert results[name] != results["off"]
+    # both extensions together: the cache keeps the evaluator's RAW outputs, the noise goes into the
+    # priors afterwards, so noisy games are the same with and without the cache
+    s = DeviceSession(4, 20, 6.6, 0.01)
+    s.set_games(reqs)
+    s.set_dirichlet(0.3, 0.25)
+    s.set_eval_cache(1 << 14)
+    s.run(hash_eval_torch)
+    both = samples_by_game(s.drain_samples())
+    assert s.counters()["eval_cache_hits"] > 0
+    s.close()
+    assert both == results["on"]
 
 
 @pytest.mark.parametrize("entries,max_sims", [(1 << 16, 0), (1024, 8)])   # roomy table; tiny table (constant eviction), long trips
