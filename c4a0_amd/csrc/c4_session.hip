@@ -451,7 +451,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       if (term) {
         c4::terminal_value(term, leaf_mask, p.c_ply_penalty, v_pen, v_nopen);  // NN output ignored (mcts.rs:92-98)
       } else {
-        // only ever reached in the first simulation: a later one starts from a terminal leaf
+        // first simulation: the network's outputs; a later one gets here only on an evaluation-cache hit
         const uint32_t legal = c4::legal_mask(leaf_mask);
         const bool is_legal = sub < 7 && ((legal >> sub) & 1u);
         float logit = __uint_as_float(0xff800000u);                             // mask_policy, c4r.rs:272-286
