@@ -20,8 +20,10 @@
 //     (two board rows): 16 distinct 16-byte slots per channel group -> bank-conflict free.
 //   * D leaves the MFMA as 4 consecutive output channels per lane for one cell: bias, ReLU and
 //     the residual add happen in registers and go back to LDS as one 8-byte store.
-//   * C = 32: 8 waves per workgroup (two per SIMD), each owning 1/8 of the tiles of every layer;
-//     two tiles are in flight per wave so consecutive MFMAs never wait on their accumulator.
+//   * 8 waves per workgroup (two per SIMD).  C = 32: each owns 1/8 of the tiles of every layer, two
+//     tiles in flight per wave so consecutive MFMAs never wait on their accumulator.  C = 64: the
+//     waves work in pairs that share 1/4 of the tiles and split the output channels, so a wave
+//     holds half of a layer's weights (144 registers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -87,23 +89,23 @@ struct TowerParams {
 //     two stages a whole layer ahead, and every wavefront copies them LDS->registers at the start
 //     of the layer (eight wavefronts each pulling the same 18 KB through the vector L1 cost ~1 us
 //     per layer).  C = 64 -- requested from global memory after this layer's last epilogue.
-template <int C, int NB, bool kConv0, int TPP, typename WF, typename Hook>
+template <int C, int NB, bool kConv0, int TPP, int MTW, typename WF, typename Hook>
 __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4* __restrict__ dst, WF& wf,
                                             const float* __restrict__ bias, bool is_second, int tile_lo, int tile_hi,
-                                            int lane, Hook&& after_last_pair) {
+                                            int m0, int lane, Hook&& after_last_pair) {
   using G = Geo<C, NB>;
   constexpr int kSteps = kConv0 ? 3 : 9 * G::KC;        // MFMA k-steps (= B fragments) per tile
   const int li = lane & 15, lg = lane >> 4;
 
-  f32x4 bias4[G::MT];
+  f32x4 bias4[MTW];   // this wavefront's output-channel tiles are m0 .. m0 + MTW - 1
 #pragma unroll
-  for (int m = 0; m < G::MT; m++) {
-    const float* bp = bias + 16 * m + 4 * lg;
+  for (int m = 0; m < MTW; m++) {
+    const float* bp = bias + 16 * (m0 + m) + 4 * lg;
     bias4[m] = f32x4{bp[0], bp[1], bp[2], bp[3]};
   }
 
   struct Pair {
-    f32x4 acc[TPP][G::MT];
+    f32x4 acc[TPP][MTW];
     int bidx[TPP], slot[TPP];
     bool two, live;
   };
@@ -141,13 +143,13 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
 #pragma unroll
     for (int u = 0; u < TPP; u++)
 #pragma unroll
-      for (int m = 0; m < G::MT; m++) pr.acc[u][m] = bias4[m];
+      for (int m = 0; m < MTW; m++) pr.acc[u][m] = bias4[m];
 #pragma unroll
     for (int k = 0; k < kSteps; k++)
 #pragma unroll
       for (int u = 0; u < TPP; u++)
 #pragma unroll
-        for (int m = 0; m < G::MT; m++)
+        for (int m = 0; m < MTW; m++)
           pr.acc[u][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k][m], __builtin_bit_cast(bf16x8, fr[u][k]), pr.acc[u][m], 0, 0, 0);
   };
   // lane holds output channels 16 m + 4 lg + {0..3} of cell `slot`
@@ -157,10 +159,10 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
       const bool valid = (((pr.slot[u] - 1) & 7) != 0) && (u == 0 || pr.two);   // padded column 0 is halo
       if (valid) {
 #pragma unroll
-        for (int m = 0; m < G::MT; m++) {
+        for (int m = 0; m < MTW; m++) {
           f32x4 v = pr.acc[u][m];
           // 8-byte half of the 16-byte slot of channel group 2 m + lg/2
-          uint2* dp = reinterpret_cast<uint2*>(&dst[(2 * m + (lg >> 1)) * G::kPlane + pr.bidx[u] * kBS + pr.slot[u]]) + (lg & 1);
+          uint2* dp = reinterpret_cast<uint2*>(&dst[(2 * (m0 + m) + (lg >> 1)) * G::kPlane + pr.bidx[u] * kBS + pr.slot[u]]) + (lg & 1);
           if (is_second) {
             const uint2 old = *dp;   // bf16 x4: widen by shifting into the f32 exponent/mantissa
             const float o0 = __uint_as_float(old.x << 16), o1 = __uint_as_float(old.x & 0xffff0000u);
@@ -187,9 +189,14 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
   }
 }
 
-template <int C, int NB, int NT, int TPP>
+// MS = 1: every wavefront computes all C/16 output-channel tiles of its cell tiles.  MS = 2 (C = 64):
+// the output-channel tiles are split over two wavefronts that share the cell tiles, which halves the
+// weights a wavefront holds (144 instead of 288 registers) so that two wavefronts fit on a SIMD.
+template <int C, int NB, int NT, int TPP, int MS>
 __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   using G = Geo<C, NB>;
+  constexpr int MTW = G::MT / MS;
+  static_assert(G::MT % MS == 0 && (!G::kStageW || MS == 1), "co-tile split");
   extern __shared__ __attribute__((aligned(256))) uint8_t lds_raw[];
   uint4* X = reinterpret_cast<uint4*>(lds_raw);    // block input / residual stream
   uint4* T = X + G::kBufSlots;                     // intermediate (and the conv0 input image)
@@ -197,22 +204,23 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int m0 = (wave % MS) * MTW;                // first output-channel tile of this wavefront
   const uint32_t board0 = blockIdx.x * NB;
 
   // A fragments (weights) of the current layer, in registers; conv0 uses the first 3 k-steps
   constexpr int kWSteps = 9 * G::KC;
-  bf16x8 wf[kWSteps][G::MT];
+  bf16x8 wf[kWSteps][MTW];
 #pragma unroll
   for (int k = 0; k < 3; k++)
 #pragma unroll
-    for (int m = 0; m < G::MT; m++) wf[k][m] = p.w0[(k * G::MT + m) * 64 + lane];
+    for (int m = 0; m < MTW; m++) wf[k][m] = p.w0[(k * G::MT + m0 + m) * 64 + lane];
   const int n_layers = 2 * (int)p.n_blocks;
   auto load_layer_weights = [&](int layer) __attribute__((always_inline)) {   // layer >= 1: [t][m][kc][lane]
     const bf16x8* wl = p.w + (size_t)(layer - 1) * G::kWFrags * 64;
 #pragma unroll
     for (int k = 0; k < kWSteps; k++)
 #pragma unroll
-      for (int m = 0; m < G::MT; m++) wf[k][m] = wl[(((k / G::KC) * G::MT + m) * G::KC + (k % G::KC)) * 64 + lane];
+      for (int m = 0; m < MTW; m++) wf[k][m] = wl[(((k / G::KC) * G::MT + m0 + m) * G::KC + (k % G::KC)) * 64 + lane];
   };
   // C = 32: LDS stage for one layer's fragments, same [t][m][kc][lane] order as global memory
   uint4* Wst = T + G::kBufSlots;
@@ -228,8 +236,8 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
 #pragma unroll
     for (int k = 0; k < kWSteps; k++)
 #pragma unroll
-      for (int m = 0; m < G::MT; m++)
-        wf[k][m] = __builtin_bit_cast(bf16x8, ws[(((k / G::KC) * G::MT + m) * G::KC + (k % G::KC)) * 64 + lane]);
+      for (int m = 0; m < MTW; m++)
+        wf[k][m] = __builtin_bit_cast(bf16x8, ws[(((k / G::KC) * G::MT + m0 + m) * G::KC + (k % G::KC)) * 64 + lane]);
   };
   if (G::kStageW) stage_layer_weights(1);
 
@@ -250,13 +258,13 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   __syncthreads();
 
   // tiles of this wave: a contiguous range
-  constexpr int kWaves = NT / 64;
+  constexpr int kWaves = NT / 64 / MS;             // wavefronts (or MS-groups of them) that share out the cell tiles
   constexpr int kTilesPerWave = (G::kTiles + kWaves - 1) / kWaves;
-  const int tile_lo = wave * kTilesPerWave;
+  const int tile_lo = (wave / MS) * kTilesPerWave;
   const int tile_hi = (tile_lo + kTilesPerWave < G::kTiles) ? tile_lo + kTilesPerWave : G::kTiles;
 
   // conv0: input image (T) -> X
-  tower_layer<C, NB, true, TPP>(T, X, wf, p.bias, false, tile_lo, tile_hi, lane, [&]() __attribute__((always_inline)) {
+  tower_layer<C, NB, true, TPP, MTW>(T, X, wf, p.bias, false, tile_lo, tile_hi, m0, lane, [&]() __attribute__((always_inline)) {
     if (!G::kStageW && n_layers >= 1) load_layer_weights(1);
   });
   if (G::kStageW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's share of the staged layer has landed
@@ -269,8 +277,8 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
       stage_layer_weights(layer + 1);
       fetch_staged_weights(layer);
     }
-    tower_layer<C, NB, false, TPP>(
-        is_second ? T : X, is_second ? X : T, wf, p.bias + (size_t)layer * C, is_second, tile_lo, tile_hi, lane,
+    tower_layer<C, NB, false, TPP, MTW>(
+        is_second ? T : X, is_second ? X : T, wf, p.bias + (size_t)layer * C, is_second, tile_lo, tile_hi, m0, lane,
         [&]() __attribute__((always_inline)) {
           if (!G::kStageW && layer < n_layers) load_layer_weights(layer + 1);
         });
@@ -311,7 +319,7 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   if (channels == 32) {
     constexpr int NB = 16;
     constexpr int kLds = Geo<32, NB>::kLdsBytes;
-    auto k = c4_conv_tower_kernel<32, NB, 512, 2>;   // 8 waves: two per SIMD, measured best (49 -> 32 us)
+    auto k = c4_conv_tower_kernel<32, NB, 512, 2, 1>;   // 8 waves: two per SIMD, measured best (49 -> 32 us)
     const int nt = 512;
     static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
     if (!lds_opt_in) {
@@ -325,14 +333,14 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   } else if (channels == 64) {
     constexpr int NB = 8;
     constexpr int kLds = Geo<64, NB>::kLdsBytes;
-    auto k = c4_conv_tower_kernel<64, NB, 256, 1>;   // weights alone take 288 registers: one wave per SIMD
+    auto k = c4_conv_tower_kernel<64, NB, 512, 1, 2>;   // 8 wavefronts: pairs split the output channels, two per SIMD
     static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
     if (!lds_opt_in) {
       e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
       lds_opt_in = (e == hipSuccess);
     }
     if (e == hipSuccess) {
-      k<<<dim3((n_boards + NB - 1) / NB), dim3(256), kLds, (hipStream_t)stream>>>(p);
+      k<<<dim3((n_boards + NB - 1) / NB), dim3(512), kLds, (hipStream_t)stream>>>(p);
       e = hipGetLastError();
     }
   } else {
