@@ -202,3 +202,46 @@ def test_lazy_results_and_bulk_arrays_agree_with_objects():
     planes2, pol2, qp2, qn2, gidx2 = lazy.to_arrays()                 # same answer from the object path
     assert np.array_equal(planes, planes2) and np.array_equal(pol, pol2) and np.array_equal(gidx, gidx2)
     assert PlayGamesResult.from_cbor(lazy.to_cbor()) == lazy
+
+
+def test_cbor_round_trip_property():
+    """Property test (the reference uses proptest for its own invariants): any PlayGamesResult --
+    ids across the whole u64 range, bitboards, f32 values incl. half-representable ones, signed
+    zeros, subnormals and infinities -- survives to_cbor/from_cbor bit for bit, re-encodes to the
+    same bytes, and concatenation commutes with encoding of the parts' results."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from c4a0_amd.results import GameMetadata, GameResult, PlayGamesResult, Sample
+
+    u64 = st.integers(0, (1 << 64) - 1)
+    f32 = st.one_of(st.floats(width=32, allow_nan=False), st.sampled_from([0.5, 0.25, -0.0, 1.0 / 7.0, 65504.0, 2.0 ** -24, float("inf")]))
+
+    @st.composite
+    def samples(draw):
+        mask = draw(st.integers(0, (1 << 42) - 1))
+        value = draw(st.integers(0, (1 << 42) - 1)) & mask
+        pol = np.array(draw(st.lists(f32, min_size=7, max_size=7)), dtype=np.float32)
+        return Sample(mask, value, pol, np.float32(draw(f32)), np.float32(draw(f32)))
+
+    games = st.builds(lambda a, b, c, ss: GameResult(GameMetadata(a, b, c), ss), u64, u64, u64, st.lists(samples(), max_size=4))
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(games, max_size=4), st.lists(games, max_size=3))
+    def check(g1, g2):
+        a, b = PlayGamesResult(g1), PlayGamesResult(g2)
+        for r in (a, b, a + b):
+            enc = r.to_cbor()
+            back = PlayGamesResult.from_cbor(enc)
+            assert back.to_cbor() == enc
+            assert len(back.results) == len(r.results)
+            for x, y in zip(back.results, r.results):
+                assert (x.metadata.game_id, x.metadata.player0_id, x.metadata.player1_id) == \
+                       (y.metadata.game_id, y.metadata.player0_id, y.metadata.player1_id)
+                assert len(x.samples) == len(y.samples)
+                for s, t in zip(x.samples, y.samples):
+                    assert (s.mask, s.value) == (t.mask, t.value)
+                    assert np.asarray(s.policy, np.float32).tobytes() == np.asarray(t.policy, np.float32).tobytes()
+                    assert np.float32(s.q_penalty).tobytes() == np.float32(t.q_penalty).tobytes()
+                    assert np.float32(s.q_no_penalty).tobytes() == np.float32(t.q_no_penalty).tobytes()
+
+    check()
