@@ -107,14 +107,13 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
   struct Pair {
     f32x4 acc[TPP][MTW];
     int bidx[TPP], slot[TPP];
-    bool two, live;
+    int n_live;          // tiles of this group that exist (the last group of a wavefront may be short)
   };
   auto geom = [&](int tile, Pair& pr) __attribute__((always_inline)) {
-    pr.live = tile < tile_hi;
-    pr.two = tile + 1 < tile_hi;
+    pr.n_live = tile_hi - tile < TPP ? tile_hi - tile : TPP;
 #pragma unroll
     for (int u = 0; u < TPP; u++) {
-      const int tl = (u == 1 && !pr.two) ? tile : tile + u;
+      const int tl = u < pr.n_live ? tile + u : tile;   // a missing tile recomputes the first one (never stored)
       pr.bidx[u] = tl / kTilesPerBoard;
       pr.slot[u] = 9 + 16 * (tl - pr.bidx[u] * kTilesPerBoard) + li;   // cell_slot of the tile's first cell is 9 + 16 j
     }
@@ -156,7 +155,7 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
   auto epilogue = [&](const Pair& pr) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < TPP; u++) {
-      const bool valid = (((pr.slot[u] - 1) & 7) != 0) && (u == 0 || pr.two);   // padded column 0 is halo
+      const bool valid = (((pr.slot[u] - 1) & 7) != 0) && u < pr.n_live;   // padded column 0 is halo
       if (valid) {
 #pragma unroll
         for (int m = 0; m < MTW; m++) {
@@ -316,7 +315,25 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   if (n_boards == 0) return C4_OK;
   TowerParams p{(const uint16_t*)planes_dev, (const bf16x8*)w0_dev, (const bf16x8*)w_dev, bias_dev, (uint16_t*)out_dev, n_boards, n_blocks};
   hipError_t e = hipSuccess;
-  if (channels == 32) {
+  if (channels == 32 && n_boards <= 8 * 160) {
+    // small launches (up to 1 280 boards): 8 boards per workgroup, three tiles in flight per wave, so
+    // that the launch spreads over twice as many CUs (2 048 boards alone: 31.6 -> 20.5 us).  NOT used for
+    // the 2 048-board launches of two concurrent sessions: there the other session fills the rest of
+    // the chip and what counts is CU-time per board, which is 30 % higher this way (measured: -1.7 %
+    // games/s at BASELINE config 2).
+    constexpr int NB = 8;
+    constexpr int kLds = Geo<32, NB>::kLdsBytes;
+    auto k = c4_conv_tower_kernel<32, NB, 512, 3, 1>;
+    static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
+    if (!lds_opt_in) {
+      e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      lds_opt_in = (e == hipSuccess);
+    }
+    if (e == hipSuccess) {
+      k<<<dim3((n_boards + NB - 1) / NB), dim3(512), kLds, (hipStream_t)stream>>>(p);
+      e = hipGetLastError();
+    }
+  } else if (channels == 32) {
     constexpr int NB = 16;
     constexpr int kLds = Geo<32, NB>::kLdsBytes;
     auto k = c4_conv_tower_kernel<32, NB, 512, 2, 1>;   // 8 waves: two per SIMD, measured best (49 -> 32 us)
