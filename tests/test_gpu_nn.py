@@ -37,7 +37,7 @@ def _ref_tower(model, x):
     return y
 
 
-@pytest.mark.parametrize("channels,blocks,n", [(32, 1, 37), (32, 4, 4096), (64, 2, 100), (64, 8, 512)])
+@pytest.mark.parametrize("channels,blocks,n", [(32, 1, 37), (32, 4, 1003), (32, 4, 4096), (64, 2, 100), (64, 8, 512)])
 def test_hip_conv_tower_vs_fp32_reference(channels, blocks, n):
     from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
 
