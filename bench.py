@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--eager", action="store_true", help="no HIP graph: launch every kernel from the host")
-    ap.add_argument("--steps-per-graph", type=int, default=8)
+    ap.add_argument("--steps-per-graph", type=int, default=32, help="lock-step rounds per HIP-graph replay (measured: 8 -> 23.9 k, 32 -> 24.5 k, 128 -> 23.8 k games/s)")
     ap.add_argument("--one-sim-per-step", action="store_true",
                     help="A/B knob: C4_FLAG_ONE_SIM_PER_STEP (no same-launch simulation for terminal leaves)")
     ap.add_argument("--instrumented-steps", type=int, default=300, help="event-bracketed launches for the roofline object")
