@@ -105,9 +105,9 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=13500,
+    ap.add_argument("--steps", type=int, default=13504,
                     help="timed lock-step rounds; the default completes >= 10 x 4096 games in the timed region (SURVEY 8d, C2)")
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=192)
     ap.add_argument("--games-per-gpu", type=int, default=4096, help="resident games per GPU (BASELINE config 2: 4096)")
     ap.add_argument("--n-mcts", type=int, default=100)
     ap.add_argument("--blocks", type=int, default=4, help="residual blocks")
