@@ -65,6 +65,8 @@ SIGNATURES = {
     "c4_session_set_dirichlet": (C.c_int, [_vp, C.c_float, C.c_float]),
     "c4_session_bind_leaf_models": (C.c_int, [_vp, _vp]),
     "c4_session_set_eval_cache": (C.c_int, [_vp, C.c_uint64, C.c_uint32]),
+    "c4_session_progress": (C.c_int, [_vp, _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint32)]),
+    "c4_session_compact": (C.c_int, [_vp, C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
     "c4_session_start": (C.c_int, [_vp]),
     "c4_session_step": (C.c_int, [_vp]),
     "c4_session_set_timing": (C.c_int, [_vp, C.c_int]),

@@ -189,6 +189,7 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
             stats.update(sess.counters())
             stats["steps"] = steps
             stats["n_slots"] = n_slots
+            stats["rows_at_end"] = sess.rows
             stats["concurrent_sessions"] = 1
     finally:
         sess.close()
@@ -236,6 +237,7 @@ def _play_concurrently(reqs, parts, n_slots, n_mcts_iterations, c_exploration, c
             stats.update(tot)
             stats["steps"] = max(steps)
             stats["n_slots"] = sum(s.n_slots for s in sessions)
+            stats["rows_at_end"] = sum(s.rows for s in sessions)
             stats["concurrent_sessions"] = parts
     finally:
         for s in sessions:

@@ -795,6 +795,54 @@ __global__ void k_dirichlet(const uint64_t* game_id, const uint32_t* n_moves, co
   for (int c = 0; c < 7; c++) eta[7 * i + c] = e[c];
 }
 
+// ------------------------------------------------------------------------------------------
+// Tail compaction: once the request queue is empty, finished slots stay empty and the evaluator
+// would keep computing rows for them.  k_compact_plan pairs every active slot beyond the first A
+// slots (A = number of active games) with an idle slot below A; k_compact_move copies the game
+// (slot state, the used part of its arena, its evaluator input row) across.  All references inside
+// a game's state are arena-relative, so nothing needs patching.
+// ------------------------------------------------------------------------------------------
+struct CompactPlan {
+  uint32_t n_active;
+  uint32_t n_pairs;
+};
+__global__ __launch_bounds__(1024) void k_compact_plan(const Slot* slots, uint32_t n_slots, CompactPlan* plan, uint2* pairs) {
+  __shared__ uint32_t s_active, s_holes, s_movers;
+  if (threadIdx.x == 0) { s_active = 0; s_holes = 0; s_movers = 0; }
+  __syncthreads();
+  uint32_t mine = 0;
+  for (uint32_t g = threadIdx.x; g < n_slots; g += blockDim.x) mine += slots[g].status == kActive ? 1u : 0u;
+  atomicAdd(&s_active, mine);
+  __syncthreads();
+  const uint32_t A = s_active;
+  // any bijection between holes (< A, idle) and movers (>= A, active) will do: which slot plays a
+  // game changes nothing a game records
+  for (uint32_t g = threadIdx.x; g < n_slots; g += blockDim.x) {
+    const bool act = slots[g].status == kActive;
+    if (g < A && !act) pairs[atomicAdd(&s_holes, 1u)].y = g;
+    if (g >= A && act) pairs[atomicAdd(&s_movers, 1u)].x = g;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { plan->n_active = A; plan->n_pairs = s_movers; }
+}
+
+template <typename PlaneT>
+__global__ __launch_bounds__(256) void k_compact_move(Params p, const CompactPlan* plan, const uint2* pairs) {
+  const uint32_t k = blockIdx.x;
+  if (k >= plan->n_pairs) return;
+  const uint32_t src = pairs[k].x, dst = pairs[k].y;
+  const Slot* ss = p.slots + src;
+  const uint32_t n_blocks = ss->n_blocks;
+  const uint4* sb = reinterpret_cast<const uint4*>(p.blocks + (size_t)src * p.blocks_per_slot);
+  uint4* db = reinterpret_cast<uint4*>(p.blocks + (size_t)dst * p.blocks_per_slot);
+  for (uint32_t i = threadIdx.x; i < n_blocks * 8u; i += blockDim.x) db[i] = sb[i];
+  PlaneT* pl = reinterpret_cast<PlaneT*>(p.planes);
+  for (uint32_t e = threadIdx.x; e < C4_PLANES_LEN; e += blockDim.x) pl[(size_t)dst * C4_PLANES_LEN + e] = pl[(size_t)src * C4_PLANES_LEN + e];
+  if (threadIdx.x < 16) reinterpret_cast<uint4*>(p.slots + dst)[threadIdx.x] = reinterpret_cast<const uint4*>(ss)[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) { p.slots[src].status = kIdle; p.slots[src].ordinal = 0xFFFFFFFFu; }
+}
+
 // K6: pack finished games' records contiguously (one wavefront per game, 4 records per pass)
 __global__ __launch_bounds__(64) void k_pack_samples(const c4_sample_rec* src, const uint32_t* counts,
                                                      const unsigned long long* offsets, uint64_t n_games, c4_sample_rec* dst) {
@@ -829,7 +877,8 @@ struct c4_session {
   c4_config cfg{};
   Params p{};
   hipStream_t stream = nullptr;
-  uint32_t n_waves = 0;
+  uint32_t n_waves = 0;       // wavefronts a step launches now (shrinks with c4_session_compact)
+  uint32_t n_waves_cap = 0;   // as created: size of the per-wavefront arrays
   uint32_t seq = 0;
   bool timing = true;
   bool bound = false, have_games = false;
@@ -842,7 +891,10 @@ struct c4_session {
   hipEvent_t probe_event = nullptr;
   bool probe_pending = false;
   uint64_t probe_done = 0;
+  uint64_t probe_started = 0;
   uint32_t probe_error = 0;
+  CompactPlan* plan_dev = nullptr;   // tail compaction scratch
+  uint2* pairs_dev = nullptr;
 };
 
 extern "C" {
@@ -874,7 +926,7 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
   if (bps > kMaxBlocksPerSlot) bps = kMaxBlocksPerSlot;   // n_mcts_iterations > 1523: overflow is still detected per slot
   s->cfg.blocks_per_slot = (uint32_t)bps;
   const size_t n = cfg->n_slots;
-  s->n_waves = (uint32_t)((n + 7) / 8);
+  s->n_waves = s->n_waves_cap = (uint32_t)((n + 7) / 8);
   Params& p = s->p;
   p.n_slots = cfg->n_slots;
   p.blocks_per_slot = (uint32_t)bps;
@@ -916,6 +968,7 @@ int c4_session_destroy(c4_session* s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream); else (void)hipDeviceSynchronize();
   (void)hipFree(s->p.slots); (void)hipFree(s->p.blocks); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob); (void)hipFree(s->p.stamps); (void)hipFree(s->p.clock_acc); (void)hipFree(s->p.phase);
   (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts); (void)hipFree(s->p.cache);
+  (void)hipFree(s->plan_dev); (void)hipFree(s->pairs_dev);
   (void)hipFree(s->reqs_dev); (void)hipFree(s->start_mask_dev); (void)hipFree(s->start_value_dev);
   if (s->probe_host) (void)hipHostFree(s->probe_host);
   if (s->probe_event) (void)hipEventDestroy(s->probe_event);
@@ -946,17 +999,19 @@ int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n
     HIP_TRY(hipMemcpy(s->start_mask_dev, start_masks, n_games * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->start_value_dev, start_values, n_games * 8, hipMemcpyHostToDevice));
   }
+  s->p.n_slots = s->cfg.n_slots;   // a compacted session goes back to its full width
+  s->n_waves = s->p.n_waves = s->n_waves_cap;
   Globals g0{};
   g0.queue_head = n_games < s->cfg.n_slots ? n_games : s->cfg.n_slots;
   HIP_TRY(hipMemcpy(s->p.glob, &g0, sizeof g0, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(s->p.wave_ctr, 0, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(s->p.wave_ctr, 0, (size_t)s->n_waves_cap * CTR_N * sizeof(unsigned long long)));
   s->p.reqs = s->reqs_dev;
   s->p.start_mask = s->start_mask_dev;
   s->p.start_value = s->start_value_dev;
   s->p.n_games = n_games;
   s->n_games = n_games;
   s->have_games = true;
-  HIP_TRY(hipMemset(s->p.stamps, 0, (size_t)s->n_waves * 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(s->p.stamps, 0, (size_t)s->n_waves_cap * 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(s->p.clock_acc, 0, 2 * sizeof(unsigned long long)));
   // a new list of games may come with new evaluator weights: forget the old evaluations
   if (s->p.cache) HIP_TRY(hipMemset(s->p.cache, 0, ((size_t)s->p.cache_mask + 1) * 64));
@@ -1049,7 +1104,7 @@ int c4_session_set_timing(c4_session* s, int enable) {
   HIP_TRY(hipSetDevice(s->cfg.device));
   HIP_TRY(hipStreamSynchronize(s->stream));
   // fold nothing across the switch: restart the stamp buffers
-  HIP_TRY(hipMemset(s->p.stamps, 0, (size_t)s->n_waves * 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(s->p.stamps, 0, (size_t)s->n_waves_cap * 4 * sizeof(unsigned long long)));
   if (enable && !s->timing) s->seq = 0;
   s->timing = enable != 0;
   return C4_OK;
@@ -1059,12 +1114,12 @@ int c4_session_counters(c4_session* s, c4_counters* out) {
   if (!s || !out) return fail(C4_ERR_BAD_ARG, "null argument");
   HIP_TRY(hipSetDevice(s->cfg.device));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  std::vector<unsigned long long> h((size_t)s->n_waves * CTR_N);
+  std::vector<unsigned long long> h((size_t)s->n_waves_cap * CTR_N);   // waves retired by a compaction keep their counts
   HIP_TRY(hipMemcpy(h.data(), s->p.wave_ctr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   Globals g{};
   HIP_TRY(hipMemcpy(&g, s->p.glob, sizeof g, hipMemcpyDeviceToHost));
   unsigned long long sum[CTR_N] = {0};
-  for (size_t w = 0; w < s->n_waves; w++)
+  for (size_t w = 0; w < s->n_waves_cap; w++)
     for (int k = 0; k < CTR_N; k++) sum[k] += h[w * CTR_N + k];
   memset(out, 0, sizeof *out);
   out->sims = sum[CTR_SIMS]; out->select_levels = sum[CTR_S]; out->backup_nodes = sum[CTR_K];
@@ -1093,6 +1148,7 @@ int c4_session_poll(c4_session* s, uint64_t* games_done, uint32_t* error) {
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
   if (s->probe_pending && hipEventQuery(s->probe_event) == hipSuccess) {
     s->probe_done = s->probe_host->games_done;
+    s->probe_started = s->probe_host->queue_head < s->n_games ? s->probe_host->queue_head : s->n_games;
     s->probe_error = s->probe_host->error;
     s->probe_pending = false;
   }
@@ -1103,6 +1159,50 @@ int c4_session_poll(c4_session* s, uint64_t* games_done, uint32_t* error) {
   }
   if (games_done) *games_done = s->probe_done;
   if (error) *error = s->probe_error;
+  return C4_OK;
+}
+
+int c4_session_progress(c4_session* s, uint64_t* games_done, uint64_t* games_started, uint32_t* error) {
+  const int rc = c4_session_poll(s, games_done, error);
+  if (rc == C4_OK && games_started) *games_started = s->probe_started;
+  return rc;
+}
+
+int c4_session_compact(c4_session* s, uint32_t multiple, uint32_t* n_active, uint32_t* n_slots_now) {
+  if (!s || !s->bound || !s->have_games) return fail(C4_ERR_BAD_ARG, "compact needs a bound session with games");
+  if (s->p.leaf_models) return fail(C4_ERR_BAD_ARG, "compaction does not move the per-slot model ids of multi-model sessions");
+  if (multiple == 0 || multiple % 8) return fail(C4_ERR_BAD_ARG, "multiple must be a positive multiple of 8");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  Globals g{};
+  HIP_TRY(hipMemcpy(&g, s->p.glob, sizeof g, hipMemcpyDeviceToHost));
+  if (n_slots_now) *n_slots_now = s->p.n_slots;
+  if (g.queue_head < s->n_games) {   // slots are still being refilled: nothing to gain
+    if (n_active) *n_active = s->p.n_slots;
+    return C4_OK;
+  }
+  if (!s->plan_dev) {
+    HIP_TRY(hipMalloc(&s->plan_dev, sizeof(CompactPlan)));
+    HIP_TRY(hipMalloc(&s->pairs_dev, (size_t)s->cfg.n_slots * sizeof(uint2)));
+  }
+  hipLaunchKernelGGL(k_compact_plan, dim3(1), dim3(1024), 0, s->stream, s->p.slots, s->p.n_slots, s->plan_dev, s->pairs_dev);
+  const uint32_t max_pairs = s->p.n_slots / 2 + 1;
+  if (s->cfg.planes_dtype == 0) hipLaunchKernelGGL(k_compact_move<float>, dim3(max_pairs), dim3(256), 0, s->stream, s->p, s->plan_dev, s->pairs_dev);
+  else hipLaunchKernelGGL(k_compact_move<uint16_t>, dim3(max_pairs), dim3(256), 0, s->stream, s->p, s->plan_dev, s->pairs_dev);
+  HIP_TRY(hipGetLastError());
+  CompactPlan plan{};
+  HIP_TRY(hipMemcpyAsync(&plan, s->plan_dev, sizeof plan, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  uint32_t want = ((plan.n_active + multiple - 1) / multiple) * multiple;
+  if (want < multiple) want = multiple;
+  if (want < s->p.n_slots) {
+    s->p.n_slots = want;
+    s->n_waves = (want + 7) / 8;
+    s->p.n_waves = s->n_waves;
+    HIP_TRY(hipMemset(s->p.stamps, 0, (size_t)s->n_waves_cap * 4 * sizeof(unsigned long long)));   // the stamp stride changed
+  }
+  if (n_active) *n_active = plan.n_active;
+  if (n_slots_now) *n_slots_now = s->p.n_slots;
   return C4_OK;
 }
 

@@ -47,6 +47,7 @@ class DeviceSession:
             self.logprobs = torch.zeros((self.n_slots, 7), dtype=torch.float32, device=self.device)
             self.q = torch.zeros((self.n_slots, 2), dtype=torch.float32, device=self.device)
         self.n_games = 0
+        self.rows = self.n_slots          # slots a step launches / rows the evaluator computes (compact() narrows it)
         self._bound_stream = None
 
     # ---------------------------------------------------------------- lifetime
@@ -75,6 +76,7 @@ class DeviceSession:
             sv = (C.c_uint64 * max(1, n))(*[int(v) for _, v in start_positions])
         check(self.L.c4_session_set_games(self._h, arr, n, sm, sv))
         self.n_games = n
+        self.rows = self.n_slots
 
     def bind(self, stream: Optional[torch.cuda.Stream] = None):
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
@@ -148,6 +150,22 @@ class DeviceSession:
         check(self.L.c4_session_poll(self._h, C.byref(done), C.byref(err)))
         return done.value, err.value
 
+    def progress(self) -> Tuple[int, int, int]:
+        """poll() plus the number of games taken off the request list: (done, started, error)."""
+        done, started, err = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        check(self.L.c4_session_progress(self._h, C.byref(done), C.byref(started), C.byref(err)))
+        return done.value, started.value, err.value
+
+    def compact(self, multiple: int = 256) -> Tuple[int, int]:
+        """Tail of a job (every request started): move the remaining games into the lowest slots and
+        narrow the session to the smallest multiple of `multiple` slots holding them
+        (c4_session_compact).  Returns (active games, rows); `self.rows` rows are evaluated and stepped
+        from now on.  Graphs captured earlier are stale."""
+        act, rows = C.c_uint32(), C.c_uint32()
+        check(self.L.c4_session_compact(self._h, int(multiple), C.byref(act), C.byref(rows)))
+        self.rows = rows.value
+        return act.value, rows.value
+
     def raise_if_device_error(self):
         c = self.counters()
         if c["error"]:
@@ -193,14 +211,29 @@ class DeviceSession:
 
     # ---------------------------------------------------------------- the loop
     def evaluate(self, evaluator: DeviceEvaluator):
+        r = self.rows
+        planes, logprobs, q = (self.planes, self.logprobs, self.q) if r == self.n_slots else (self.planes[:r], self.logprobs[:r], self.q[:r])
         if getattr(evaluator, "graph_safe", False):   # writes the bound tensors in place
-            evaluator(self.planes, out_logprobs=self.logprobs, out_q=self.q)
+            evaluator(planes, out_logprobs=logprobs, out_q=q)
             return
-        lp, q = evaluator(self.planes)
-        if lp.data_ptr() != self.logprobs.data_ptr():
-            self.logprobs.copy_(lp.reshape(self.n_slots, 7))
-        if q.data_ptr() != self.q.data_ptr():
-            self.q.copy_(q.reshape(self.n_slots, 2))
+        lp, q_out = evaluator(planes)
+        if lp.data_ptr() != logprobs.data_ptr():
+            logprobs.copy_(lp.reshape(r, 7))
+        if q_out.data_ptr() != q.data_ptr():
+            q.copy_(q_out.reshape(r, 2))
+
+    def narrow_if_worthwhile(self, multiple: int = 256) -> bool:
+        """Tail of a job: when every request has been started and at most half of the rows still hold
+        a game, compact() the session.  True if `self.rows` changed (captured graphs are then stale).
+        Synchronises only when it acts."""
+        if getattr(self, "leaf_models", None) is not None or self.rows <= multiple:
+            return False
+        done, started, _err = self.progress()
+        if started < self.n_games or (self.n_games - done) > self.rows // 2:
+            return False
+        before = self.rows
+        self.compact(multiple)
+        return self.rows != before
 
     def run(self, evaluator: DeviceEvaluator, max_steps: Optional[int] = None, poll_every: int = 16,
             on_step: Optional[Callable[[int], None]] = None, steps_per_graph: int = 0) -> int:
@@ -241,6 +274,9 @@ class DeviceSession:
                     self.raise_if_device_error()
                 if done >= self.n_games:
                     break
+                if graph is not None and self.narrow_if_worthwhile():
+                    inflight.clear()
+                    graph = self.capture_steps(evaluator, steps_per_graph)   # the old graph carries the old width
             if max_steps is not None and steps >= max_steps:
                 break
         if graph is not None:
@@ -296,6 +332,9 @@ def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator
                 s.raise_if_device_error()
             if done >= s.n_games:
                 live[i] = False
+            elif s.narrow_if_worthwhile():   # tail: fewer rows to evaluate, see DeviceSession.compact
+                inflight[i].clear()
+                graphs[i] = s.capture_steps(evaluator, steps_per_graph, stream=st)
     torch.cuda.synchronize(dev)
     for s in sessions:
         s.set_timing(True)

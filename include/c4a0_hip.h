@@ -170,6 +170,18 @@ int c4_session_counters(c4_session* s, c4_counters* out);
 /* Non-blocking completion probe: enqueues a copy of (games_done, error) to pinned host
  * memory; *games_done / *error hold the values of the previous probe that has landed. */
 int c4_session_poll(c4_session* s, uint64_t* games_done, uint32_t* error);
+/* The same probe, also reporting how many games have been taken off the request list so far. */
+int c4_session_progress(c4_session* s, uint64_t* games_done, uint64_t* games_started, uint32_t* error);
+
+/* Tail of a job: once every request has been started, finished slots stay empty while the evaluator
+ * still computes rows for them.  Moves the remaining active games into the lowest slots (slot state,
+ * arena, evaluator input row; which slot plays a game changes none of its samples) and narrows the
+ * session to the smallest multiple of `multiple` (itself a multiple of 8) slots that holds them:
+ * c4_session_step then launches that many slots and the caller evaluates only rows [0, *n_slots_now).
+ * A no-op (returning the unchanged width) while requests are still queued.  Not for sessions with
+ * c4_session_bind_leaf_models.  HIP graphs captured before the call carry the old width: re-capture.
+ * c4_session_set_games restores the full width.  Synchronises. */
+int c4_session_compact(c4_session* s, uint32_t multiple, uint32_t* n_active, uint32_t* n_slots_now);
 
 /* GameResult list (types.rs:63-71, mcts.rs:271-313).  Two-call pattern: n_samples of every
  * game (host array of n_games uint32, 0 = unfinished), then the records of finished games

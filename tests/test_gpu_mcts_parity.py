@@ -347,3 +347,38 @@ def test_evaluation_cache_is_refused_for_multi_model_sessions(env):
     with pytest.raises(C4Error):
         s.bind_leaf_models()
     s.close()
+
+
+def test_tail_compaction_moves_games_without_changing_them(env):
+    """c4_session_compact: once the request list is exhausted the surviving games are moved into the
+    lowest slots (state, arena, evaluator row) and the session narrows; every sample must still
+    equal the oracle's, whatever the moments at which it is called."""
+    DeviceSession, O, dev = env
+    from tests.helpers import hash_eval_torch, oracle_samples_by_game, samples_by_game
+
+    reqs = [(3000 + i, 0, 0) for i in range(90)]
+    s = DeviceSession(64, 10, 6.6, 0.01, device=dev)
+    s.set_games(reqs)
+    s.bind()
+    s.start()
+    widths, steps = [], 0
+    while s.counters()["games_done"] < len(reqs) and steps < 20000:
+        s.evaluate(hash_eval_torch)
+        s.step()
+        steps += 1
+        if steps % 7 == 0:
+            act, rows = s.compact(8)
+            widths.append(rows)
+            assert act <= rows <= 64 and rows % 8 == 0 and rows == s.rows
+            m, v, status = s.leaves()
+            assert (status[:act] == 1).all() or rows == 64          # compacted: the games sit in the first slots
+    got = samples_by_game(s.drain_samples())
+    c = s.counters()
+    # a new list of games restores the full width
+    s.set_games(reqs[:3])
+    assert s.rows == 64
+    s.close()
+    assert widths[0] == 64 and widths[-1] == 8 and sorted(widths, reverse=True) == widths   # no-op while requests are queued, then it narrows
+    ores, ost = O.self_play(reqs, 1 << 20, 10, 6.6, 0.01, "hash")
+    assert got == oracle_samples_by_game(ores)
+    assert c["sims"] + c["ref_skipped_sims"] == ost["sims"] and c["moves"] == ost["moves"] and c["games_done"] == 90

@@ -276,3 +276,26 @@ def test_device_resident_training_tensors_equal_the_reference_conversion():
     for i, smp in enumerate(samples):
         a, b, c, d = smp.to_numpy()
         assert np.array_equal(pos[i], a) and np.array_equal(policy[i], b) and qp[i] == c and qn[i] == d
+
+
+def test_play_games_narrows_the_tail_without_changing_samples():
+    """Device mode narrows a session when at most half of its rows still hold a game
+    (DeviceSession.narrow_if_worthwhile -> c4_session_compact + a fresh HIP graph).  A run wide
+    enough to narrow several times must give the samples of a run too small ever to narrow."""
+    import c4a0_amd
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 2, 2)), dev, dtype=torch.bfloat16)
+    reqs = [c4a0_amd.GameMetadata(9000 + i, 0, 0) for i in range(1500)]
+    st_wide, st_two, st_small = {}, {}, {}
+    wide = c4a0_amd.play_games(reqs, 64, 6, 6.6, 0.01, evaluator=net, resident_games=1024, concurrent_sessions=1, stats=st_wide)
+    two = c4a0_amd.play_games(reqs, 64, 6, 6.6, 0.01, evaluator=net, resident_games=2048, concurrent_sessions=2, stats=st_two)
+    small = c4a0_amd.play_games(reqs, 64, 6, 6.6, 0.01, evaluator=net, resident_games=128, concurrent_sessions=1, stats=st_small)
+    a = small.to_arrays()
+    for other in (wide, two):
+        for x, y in zip(a, other.to_arrays()):
+            assert np.array_equal(x, y)
+    assert st_wide["sims"] == st_small["sims"] == st_two["sims"]
+    assert st_wide["rows_at_end"] < 1024 and st_small["rows_at_end"] == 128
