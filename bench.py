@@ -158,7 +158,7 @@ def main():
     # games are split over P sessions (c4a0_amd.session.run_sessions explains why), session p taking
     # every P-th of the rank's requests
     ids = [rank + world * i for i in range(n_games)]
-    sessions, streams, graphs = [], [], []
+    sessions, streams, graphs, graphs1 = [], [], [], []   # graphs1: one round per replay, for the K % U remainder
     U = 1 if args.eager else max(1, args.steps_per_graph)
     for p in range(P):
         sp = DeviceSession((G + P - 1 - p) // P, n_iter, 6.6, 0.01, device=device, planes_dtype=torch.bfloat16,
@@ -174,8 +174,10 @@ def main():
         if args.eager:
             sp.set_timing(False)
             graphs.append(None)
+            graphs1.append(None)
         else:
             graphs.append(sp.capture_steps(net, U, stream=st if P > 1 else None))
+            graphs1.append(sp.capture_steps(net, 1, stream=st if P > 1 else None) if U > 1 else graphs[-1])
         sessions.append(sp)
         streams.append(st)
 
@@ -202,10 +204,13 @@ def main():
                 with torch.cuda.stream(st):
                     g.replay()
         for _ in range(k % U if graphs[0] is not None else k):
-            for sp, st in zip(sessions, streams):
+            for sp, st, g1 in zip(sessions, streams, graphs1):
                 with torch.cuda.stream(st):
-                    sp.evaluate(net)
-                    sp.step()
+                    if g1 is not None:
+                        g1.replay()
+                    else:
+                        sp.evaluate(net)
+                        sp.step()
 
     run_steps(preroll)
     run_steps(args.warmup)
