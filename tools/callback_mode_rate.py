@@ -29,6 +29,7 @@ res2 = c4a0_amd.play_games(reqs, 4096, 100, 6.6, 0.01, evaluator=net, stats=stat
 dt = time.perf_counter() - t0
 print(f"device mode (default resident games = {stats['n_slots']}): {n} games: {dt:.2f} s = {n / dt:.0f} games/s, {stats['steps']} steps")
 a = res.to_arrays()
+print("device-mode samples identical to the callback run:", all(np.array_equal(x, y) for x, y in zip(a, res2.to_arrays())))
 for name, kw in (("callback mode + evaluation cache (extension)", dict(py_eval_pos_cb=cb)), ("device mode + evaluation cache (extension)", dict(evaluator=net))):
     t0 = time.perf_counter()
     r = c4a0_amd.play_games(reqs, 4096, 100, 6.6, 0.01, eval_cache_entries=1 << 24, stats=stats, **kw)
