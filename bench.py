@@ -4,11 +4,14 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one lock-step MCTS round for every resident game: the ResNet evaluates the G leaf
+One lock-step ROUND = one MCTS simulation for every resident game: the ResNet evaluates the G leaf
 positions (HIP-graph replay, bf16) and the fused HIP step kernel consumes the outputs (expand,
 backup, move/finish/refill, select, encode the next leaves; a game whose new leaf is terminal
 runs that simulation in the same launch).  The G games are split over two sessions whose graphs
-replay concurrently on two streams (--sessions); a step advances both.  Workload at every N:
+replay concurrently on two streams (--sessions); a round advances both.  One bench "step" = R
+rounds (--rounds-per-step, R = 704 = 22 replays of the 32-round graph; `config.rounds_per_step`):
+the hot path over one batch of work large enough that `--steps 20` completes >= 10 x 4 096 games
+inside the timed region.  Workload at every N:
 BASELINE config 2 per GPU -- 4 096 concurrent games, n_mcts_iterations = 100, 4-block/32-channel
 ResNet in bf16, c_exploration 6.6, c_ply_penalty 0.01, game ids sharded id % N (weak scaling;
 config 3 is exactly this at N = 8).  Synthetic data: empty-board starts, random-init network
@@ -16,9 +19,10 @@ config 3 is exactly this at N = 8).  Synthetic data: empty-board starts, random-
 games have been replaced at least once, so the timed steps see the steady-state mix of game
 phases; `value` counts games COMPLETED inside the timed steps.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (fused tree step kernel vs HBM),
-"cpu_baseline" (the CPU oracle in the reference's topology, timed on this box's host cores),
-"nn" (evaluator FLOP rate).
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (fused tree step kernel vs HBM, always
+>= 300 event-bracketed launches), "cpu_baseline" (the CPU oracle in the reference's thread topology
+-- one evaluator thread + workers, two queues -- timed on this box's host cores), "nn" (evaluator
+FLOP rate), and for N > 1 "sample_allgather" (the path's one exchange step, merged and checked).
 """
 from __future__ import annotations
 
@@ -62,10 +66,12 @@ def usable_cores() -> int:
 
 
 def cpu_baseline(net, device, n_iter: int, threads: int, budget_s: float = 20.0):
-    """The reference's CPU path restated: tree search on host cores (oracle, OpenMP over games =
-    the MctsThreads of self_play.rs:78-106), leaves batched to the SAME network on the GPU through
-    the numpy callback round trip of nn.py:119-130.  Bounded sample of the same workload: a small
-    probe sizes the sample to about `budget_s` seconds."""
+    """The reference's CPU path restated IN ITS OWN TOPOLOGY (self_play.rs:60-106): this thread is the
+    NN thread (NNThread::loop_until_close: drain the queue, batch the unique leaves, call the
+    evaluator), `threads - 1` C worker threads are the MctsThreads, games travel over two queues, so
+    network evaluation and tree work overlap (oracle c4o_self_play_async).  The evaluator is the SAME
+    bf16 network on the GPU through the numpy callback round trip of nn.py:119-130.  Bounded sample of
+    the same workload: a small probe sizes the sample to about `budget_s` seconds."""
     from oracle import c4oracle as O
 
     def cb(_model_id, x):
@@ -74,10 +80,12 @@ def cpu_baseline(net, device, n_iter: int, threads: int, budget_s: float = 20.0)
             lp, q = lp.float().cpu().numpy(), q.float().cpu().numpy()
         return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
 
-    def run(n_games):
+    threads = max(2, threads)
+
+    def run(n_games, topology="async"):
         reqs = [(i, 0, 0) for i in range(n_games)]
         t0 = time.perf_counter()
-        _res, st = O.self_play(reqs, 4096, n_iter, 6.6, 0.01, cb, n_threads=threads)
+        _res, st = O.self_play(reqs, 4096, n_iter, 6.6, 0.01, cb, n_threads=threads, topology=topology)
         return time.perf_counter() - t0, st
 
     # grow the sample until it runs for >= budget_s / 2 (all games resident at once, as in the
@@ -86,12 +94,17 @@ def cpu_baseline(net, device, n_iter: int, threads: int, budget_s: float = 20.0)
     while dt < budget_s / 2 and n_games < 32768:
         n_games *= 2 if dt > budget_s / 8 else 4
         dt, st = run(n_games)
-    # context: the tree path alone on the host cores (uniform evaluator, no network at all)
+    # context 1: the round-1 restatement (lock-step ticks: evaluation and tree work serialised) on a quarter of the sample
+    dt_l, _st_l = run(max(256, n_games // 4), topology="lockstep")
+    # context 2: the tree path alone on the host cores (uniform evaluator, no network at all)
     t0 = time.perf_counter()
-    _r, st_u = O.self_play([(i, 0, 0) for i in range(2048)], 4096, n_iter, 6.6, 0.01, "uniform", n_threads=threads)
+    _r, st_u = O.self_play([(i, 0, 0) for i in range(2048)], 4096, n_iter, 6.6, 0.01, "uniform", n_threads=threads, topology="async")
     tree_only = st_u["sims"] / (time.perf_counter() - t0)
-    return {"value": n_games / dt, "unit": "games/s", "cores": threads, "kind": "port", "tree_only_sims_per_s": tree_only,
-            "sample": f"{n_games} games, n_mcts_iterations={n_iter}, C oracle (OpenMP x{threads}) + the same bf16 ResNet on the GPU via the numpy callback round trip; {dt:.1f} s",
+    return {"value": n_games / dt, "unit": "games/s", "cores": threads, "kind": "port",
+            "topology": f"async: 1 evaluator thread + {threads - 1} MCTS worker threads over two queues, evaluation and tree work overlapped (self_play.rs:60-106)",
+            "tree_only_sims_per_s": tree_only, "lockstep_games_per_s": max(256, n_games // 4) / dt_l,
+            "nn_calls": st["nn_calls"], "mean_nn_batch": st["nn_positions"] / max(1, st["nn_calls"]),
+            "sample": f"{n_games} games, n_mcts_iterations={n_iter}, C oracle in the reference's thread topology ({threads} threads) + the same bf16 ResNet on the GPU via the numpy callback round trip; {dt:.1f} s",
             "sims_per_s": st["sims"] / dt}
 
 
@@ -105,9 +118,11 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=13504,
-                    help="timed lock-step rounds; the default completes >= 10 x 4096 games in the timed region (SURVEY 8d, C2)")
-    ap.add_argument("--warmup", type=int, default=192)
+    ap.add_argument("--steps", type=int, default=20,
+                    help="timed steps of --rounds-per-step lock-step rounds each; 20 x 704 rounds complete >= 10 x 4096 games (SURVEY 8d, C2)")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed steps after the pre-roll")
+    ap.add_argument("--rounds-per-step", type=int, default=704,
+                    help="lock-step rounds (one MCTS simulation per resident game) per bench step; 704 = 22 replays of the 32-round HIP graph")
     ap.add_argument("--games-per-gpu", type=int, default=4096, help="resident games per GPU (BASELINE config 2: 4096)")
     ap.add_argument("--n-mcts", type=int, default=100)
     ap.add_argument("--blocks", type=int, default=4, help="residual blocks")
@@ -119,7 +134,7 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=32, help="lock-step rounds per HIP-graph replay (measured: 8 -> 23.9 k, 32 -> 24.5 k, 128 -> 23.8 k games/s)")
     ap.add_argument("--one-sim-per-step", action="store_true",
                     help="A/B knob: C4_FLAG_ONE_SIM_PER_STEP (no same-launch simulation for terminal leaves)")
-    ap.add_argument("--instrumented-steps", type=int, default=300, help="event-bracketed launches for the roofline object")
+    ap.add_argument("--instrumented-steps", type=int, default=320, help="event-bracketed step-kernel launches for the roofline object (>= 300 whatever --steps is)")
     ap.add_argument("--eval-cache", type=int, default=0,
                     help="EXTENSION, off by default and NOT part of the headline: evaluation-cache entries per session "
                          "(c4_session_set_eval_cache); repeated positions then skip the evaluator")
@@ -149,8 +164,10 @@ def main():
     net = InferenceNet(ConnectFourNet(cfg), device, dtype=torch.bfloat16)
 
     P = 1 if args.eager else max(1, min(args.sessions, G))
+    R = max(1, args.rounds_per_step)
+    timed_rounds, warm_rounds = args.steps * R, args.warmup * R
     preroll = args.preroll if args.preroll >= 0 else int(2.0 * 15.0 * n_iter)  # ~2 game lengths of sims
-    total_steps = preroll + args.warmup + args.steps + args.instrumented_steps + 64
+    total_steps = preroll + warm_rounds + timed_rounds + args.instrumented_steps + 64
     sims_per_game_lo = 8 * n_iter  # generous lower bound on sims per game -> upper bound on games needed
     trips = (args.eval_cache_sims or 6) if args.eval_cache else 1   # the cache lets a game run several simulations per step
     n_games = int(G * (2 + trips * total_steps / sims_per_game_lo)) + G
@@ -213,13 +230,13 @@ def main():
                         sp.step()
 
     run_steps(preroll)
-    run_steps(args.warmup)
+    run_steps(warm_rounds)
     c0 = counters()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(timed_rounds)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -234,7 +251,7 @@ def main():
     # session 0 bracketed by HIP events on its stream, and timed on the device clock inside the
     # kernel; the other sessions wait.  (Inside the graph-replayed region nothing can be bracketed
     # per launch.)
-    n_inst = max(1, min(args.steps, args.instrumented_steps))
+    n_inst = max(300, args.instrumented_steps)
     sess, st0 = sessions[0], streams[0]
     sess.set_timing(True)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_inst)]
@@ -254,21 +271,35 @@ def main():
     di = {k: ci1[k] - ci0[k] for k in ci1 if k not in ("error", "error_slot")}
     step_kernel_ms = sum(a_ev.elapsed_time(b_ev) for a_ev, b_ev in ev)
 
-    # ---- multi-GPU: the one collective of the path -- all-gather the finished samples (untimed
-    # end-of-job step; its time is reported beside the throughput)
+    # ---- multi-GPU: the one exchange step of the path -- all-gather the finished samples (untimed
+    # end-of-job step; its time is reported beside the throughput).  Exactly what
+    # c4a0_amd.distributed.play_games_sharded runs: pack on the device, counts + padded records
+    # all-gathered, shards merged into request order -- and the merged result is checked.
     allgather = None
     if dist is not None:
         try:
-            from c4a0_amd.distributed import all_gather_records
+            from c4a0_amd.api import merge_parts
+            from c4a0_amd.distributed import gather_shards, merge_shards
             torch.cuda.synchronize()
             dist.barrier()
             tg0 = time.perf_counter()
-            local = torch.cat([sp.pack_samples_device() for sp in sessions], dim=0)
-            parts = all_gather_records(local)
+            pieces = [(np.arange(p, n_games, P, dtype=np.int64), sp.sample_counts(), sp.pack_samples_device()) for p, sp in enumerate(sessions)]
+            local, local_counts = merge_parts(n_games, pieces) if P > 1 else (pieces[0][2], pieces[0][1])
+            per_rank, per_counts = gather_shards(local, local_counts, n_games * world)
+            merged, all_counts = merge_shards(per_rank, per_counts, n_games * world)
             torch.cuda.synchronize()
             tg1 = time.perf_counter()
-            allgather = {"ms": (tg1 - tg0) * 1e3, "records_per_rank": [int(p_.shape[0]) for p_ in parts],
-                         "bytes_total": int(sum(p_.numel() for p_ in parts))}
+            # request position g = i * world + rank carries game id rank + world * i = g
+            cnt = torch.as_tensor(all_counts.astype(np.int64), device=merged.device)
+            want_ids = torch.repeat_interleave(torch.arange(n_games * world, device=merged.device), cnt)
+            got_ids = merged[:, :8].contiguous().view(torch.int64).reshape(-1)
+            n_fin = int((cnt > 0).sum().item())
+            done_all = torch.tensor([float(sum(sp.counters()["games_done"] for sp in sessions))], dtype=torch.float64, device=device)
+            dist.all_reduce(done_all, op=dist.ReduceOp.SUM)
+            ok = bool(torch.equal(got_ids, want_ids)) and merged.shape[0] == int(cnt.sum().item()) and n_fin == int(done_all.item())
+            allgather = {"ms": (tg1 - tg0) * 1e3, "records_per_rank": [int(p_.shape[0]) for p_ in per_rank],
+                         "bytes_total": int(sum(p_.numel() for p_ in per_rank)), "games_merged": n_fin,
+                         "merged_in_request_order_and_complete": ok}
         except Exception as e:  # never lose the throughput line to the epilogue
             allgather = {"error": repr(e)}
 
@@ -307,6 +338,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
+            "ms_per_round": elapsed_max / timed_rounds * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -314,6 +346,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE config 2 per GPU: {G} concurrent games, n_mcts_iterations={n_iter}, "
                                    f"{cfg.n_residual_blocks}-block/{cfg.conv_filter_size}-ch ResNet bf16, c_exploration=6.6, c_ply_penalty=0.01",
+                       "rounds_per_step": R, "step": f"{R} lock-step rounds (one MCTS simulation per resident game each)",
                        "games_per_gpu": G, "n_mcts_iterations": n_iter, "parallelism": f"games sharded id%{world}",
                        "evaluator": "eager" if args.eager else f"hip-graph x{U} steps (evaluator + step kernel)",
                        "concurrent_sessions": P, "games_per_session": [sp.n_slots for sp in sessions], "preroll_steps": preroll,
@@ -330,6 +363,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "c4_step_kernel (expand+backup+move+select+encode, fused)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic,
+                         "traffic_source": "profiles/step_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, corrected per MI355X_MICROARCH.md); not re-measured in this run",
                          "avg_launch_us": avg_kernel_s * 1e6,
                          "device_clock": {"avg_kernel_us": dev_s * 1e6, "achieved": achieved_dev, "frac": achieved_dev / HBM_PEAK_GBPS,
                                           "note": "in-kernel s_memrealtime stamps; the HIP-event bracket adds the dispatch and completion latency of one launch"},
@@ -338,9 +372,9 @@ def main():
                          "bytes_per_sim": {k: v / max(1, di["sims"]) for k, v in ab.items()},
                          "S_per_sim": di["select_levels"] / max(1, di["sims"]), "K_per_sim": di["backup_nodes"] / max(1, di["sims"]),
                          "E_per_sim": di["expansions"] / max(1, di["sims"])},
-            "nn": {"bound": "mfma", "flops_per_leaf": fl, "achieved": fl * G * args.steps / elapsed / 1e12,
+            "nn": {"bound": "mfma", "flops_per_leaf": fl, "achieved": fl * G * timed_rounds / elapsed / 1e12,
                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": fl * G * args.steps / elapsed / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                   "frac": fl * G * timed_rounds / elapsed / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                    "note": "evaluator FLOPs over the WHOLE wall time of the timed steps (tree kernels and launch gaps included): a lower bound on the evaluator's own rate"},
         }
         if allgather is not None:

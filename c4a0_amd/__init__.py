@@ -11,9 +11,12 @@ from .results import GameMetadata, GameResult, PlayGamesResult, Sample  # noqa: 
 
 
 def __getattr__(name):  # torch / the HIP library are loaded on first use of the entry points
-    if name in ("play_games", "run_tui"):
+    if name in ("play_games", "run_tui", "DeviceCallback"):
         from . import api
         return getattr(api, name)
+    if name == "play_games_sharded":
+        from .distributed import play_games_sharded
+        return play_games_sharded
     raise AttributeError(name)
 
 

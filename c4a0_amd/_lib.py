@@ -57,6 +57,7 @@ _P = C.POINTER
 _vp = C.c_void_p
 SIGNATURES = {
     "c4_last_error_string": (C.c_char_p, []),
+    "c4_source_hash": (C.c_char_p, []),
     "c4_device_count": (C.c_int, [_P(C.c_int)]),
     "c4_session_create": (C.c_int, [_P(Config), _P(_vp)]),
     "c4_session_destroy": (C.c_int, [_vp]),
@@ -113,6 +114,15 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        # a library compiled from other sources than the ones beside it is refused, not used
+        # (C4A0_HIP_LIB names a diagnostic build with its own flags: not compared)
+        if "C4A0_HIP_LIB" not in os.environ:
+            from .csrc import build as _build
+
+            have, want = L.c4_source_hash().decode(), _build.source_hash()
+            if have != want:
+                raise ImportError(f"{LIB_PATH} was built from different sources (hash {have}, tree {want}): "
+                                  "rebuild it with `python c4a0_amd/csrc/build.py`")
         _lib = L
     return _lib
 

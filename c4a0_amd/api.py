@@ -119,6 +119,24 @@ class _MultiModelEvaluator:
         return lp_out, q_out
 
 
+def _validate(reqs, max_nn_batch_size, n_mcts_iterations, py_eval_pos_cb, evaluator):
+    for r in reqs:
+        if not all(hasattr(r, a) for a in ("game_id", "player0_id", "player1_id")):
+            raise TypeError("reqs must be a sequence of GameMetadata")  # reference: extract() fails, pybridge.rs:30
+    if (py_eval_pos_cb is None) == (evaluator is None):
+        raise TypeError("pass exactly one of py_eval_pos_cb (numpy callback) or evaluator= (device callable)")
+    if int(max_nn_batch_size) < 1 or int(n_mcts_iterations) < 0:
+        raise ValueError("max_nn_batch_size must be >= 1 and n_mcts_iterations >= 0")
+    multi = evaluator is not None and isinstance(evaluator, dict)
+    if evaluator is not None and not multi and any(r.player0_id != r.player1_id for r in reqs):
+        raise TypeError("games between different models need evaluator={model_id: evaluator, ...}")
+    if multi:
+        missing = {m for r in reqs for m in (r.player0_id, r.player1_id)} - set(evaluator)
+        if missing:
+            raise KeyError(f"no evaluator for model ids {sorted(missing)}")
+    return multi
+
+
 def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iterations: int,
                c_exploration: float, c_ply_penalty: float, py_eval_pos_cb: Optional[Callable] = None, *,
                evaluator: Optional[DeviceEvaluator] = None, device=None, resident_games: Optional[int] = None,
@@ -127,29 +145,70 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
                concurrent_sessions: Optional[int] = None, eval_cache_entries: int = 0) -> PlayGamesResult:
     """Play every game of `reqs` to the end with MCTS self-play on the GPU and return the
     training samples (reference pybridge.rs:20-53).  Results are in `reqs` order (the
-    reference's order is thread-finishing order, self_play.rs:116)."""
+    reference's order is thread-finishing order, self_play.rs:116).
+
+    A callback object with a `.device_evaluator` attribute (e.g. `DeviceCallback`) is played in
+    device mode with that evaluator: an unmodified caller (training.py:179-189 passes a callable)
+    gets the fast path by wrapping its network once, without touching the call."""
     reqs = list(reqs)
-    for r in reqs:
-        if not all(hasattr(r, a) for a in ("game_id", "player0_id", "player1_id")):
-            raise TypeError("reqs must be a sequence of GameMetadata")  # reference: extract() fails, pybridge.rs:30
-    if (py_eval_pos_cb is None) == (evaluator is None):
-        raise TypeError("pass exactly one of py_eval_pos_cb (numpy callback) or evaluator= (device callable)")
-    if int(max_nn_batch_size) < 1 or int(n_mcts_iterations) < 0:
-        raise ValueError("max_nn_batch_size must be >= 1 and n_mcts_iterations >= 0")
+    if py_eval_pos_cb is not None and evaluator is None and getattr(py_eval_pos_cb, "device_evaluator", None) is not None:
+        evaluator, py_eval_pos_cb = py_eval_pos_cb.device_evaluator, None
+    _validate(reqs, max_nn_batch_size, n_mcts_iterations, py_eval_pos_cb, evaluator)
     if not reqs:
         return PlayGamesResult([])
-    multi = evaluator is not None and isinstance(evaluator, dict)
-    if evaluator is not None and not multi and any(r.player0_id != r.player1_id for r in reqs):
-        raise TypeError("games between different models need evaluator={model_id: evaluator, ...}")
-    if multi:
-        missing = {m for r in reqs for m in (r.player0_id, r.player1_id)} - set(evaluator)
-        if missing:
-            raise KeyError(f"no evaluator for model ids {sorted(missing)}")
+    metas = [GameMetadata(r.game_id, r.player0_id, r.player1_id) for r in reqs]
+    recs, counts = _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator,
+                         device, resident_games, planes_dtype, blocks_per_slot, stats, dirichlet, concurrent_sessions,
+                         eval_cache_entries, on_device=False)
+    return results_from_records(metas, recs, counts)
 
+
+def merge_parts(n_games: int, parts):
+    """Interleave packed sample records back into request order.
+
+    parts = [(positions int64[k], counts uint32[k], records)] where `records` holds the records of
+    requests positions[0], positions[1], ... back to back.  Works on numpy structured arrays
+    (SAMPLE_DTYPE) and on torch uint8[n, 64] tensors (any device); vectorised, no per-game loop.
+    Returns (records in request order, counts[n_games])."""
+    from .session import SAMPLE_DTYPE
+
+    if parts and isinstance(parts[0][2], torch.Tensor):
+        dev = parts[0][2].device
+        counts = torch.zeros(n_games, dtype=torch.int64, device=dev)
+        for pos, c, _ in parts:
+            counts[torch.as_tensor(pos, device=dev)] = torch.as_tensor(np.asarray(c).astype(np.int64), device=dev)
+        starts = torch.cumsum(counts, 0) - counts
+        out = torch.zeros((int(counts.sum().item()), 64), dtype=torch.uint8, device=dev)
+        for pos, c, recs in parts:
+            c64 = torch.as_tensor(np.asarray(c).astype(np.int64), device=dev)
+            src0 = torch.cumsum(c64, 0) - c64
+            dst = torch.repeat_interleave(starts[torch.as_tensor(pos, device=dev)] - src0, c64) + torch.arange(recs.shape[0], device=dev)
+            out[dst] = recs
+        return out, counts.to(torch.int32).cpu().numpy().astype(np.uint32)
+    counts = np.zeros(n_games, dtype=np.uint32)
+    for pos, c, _ in parts:
+        counts[pos] = c
+    starts = np.concatenate([[0], np.cumsum(counts, dtype=np.int64)])      # first record of request i in the merged array
+    out = np.zeros(int(starts[-1]), dtype=SAMPLE_DTYPE)
+    for pos, c, recs in parts:
+        c64 = np.asarray(c).astype(np.int64)
+        src0 = np.cumsum(c64) - c64
+        dst = np.repeat(starts[:-1][pos] - src0, c64) + np.arange(len(recs), dtype=np.int64)
+        out[dst] = recs
+    return out, counts
+
+
+def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator, device,
+          resident_games, planes_dtype, blocks_per_slot, stats, dirichlet, concurrent_sessions, eval_cache_entries, on_device):
+    """Play `reqs` on ONE device.  Returns (records, counts) in request order; `records` is a numpy
+    SAMPLE_DTYPE array, or with on_device=True a uint8[n, 64] tensor that never left the GPU (packed
+    by k_pack_samples: what the sample all-gather of the multi-GPU path sends)."""
+    from .session import run_sessions
+
+    multi = evaluator is not None and isinstance(evaluator, dict)
     n_slots = min(len(reqs), int(resident_games) if resident_games else DEFAULT_RESIDENT_GAMES)
     if planes_dtype is None:   # hand a bf16 network bf16 planes (0/1 are exact): no conversion kernel per step
         planes_dtype = torch.bfloat16 if getattr(evaluator, "dtype", None) == torch.bfloat16 else torch.float32
-    metas = [GameMetadata(r.game_id, r.player0_id, r.player1_id) for r in reqs]
     graph_safe = evaluator is not None and not multi and getattr(evaluator, "graph_safe", False)
     # Device evaluators that are pure device code: the resident games are split over sessions that run
     # concurrently on their own streams (session.run_sessions), two by default when each half still
@@ -158,91 +217,79 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
     if parts > 1 and not graph_safe:
         raise TypeError("concurrent_sessions > 1 needs a graph-safe device evaluator (c4a0_amd.nn.InferenceNet)")
     parts = max(1, min(parts, n_slots))
-    if parts > 1:
-        recs, counts = _play_concurrently(reqs, parts, n_slots, n_mcts_iterations, c_exploration, c_ply_penalty, evaluator,
-                                          device, planes_dtype, blocks_per_slot, dirichlet, stats, eval_cache_entries)
-        return results_from_records(metas, recs, counts)
-
-    sess = DeviceSession(n_slots, n_mcts_iterations, c_exploration, c_ply_penalty, device=device,
-                         planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot)
-    try:
-        sess.set_games([(r.game_id, r.player0_id, r.player1_id) for r in reqs])
-        if dirichlet is not None:   # extension: (alpha, epsilon) root noise; the reference has none
-            sess.set_dirichlet(*dirichlet)
-        if eval_cache_entries:      # extension: evaluation cache, see DeviceSession.set_eval_cache
-            if multi:
-                raise TypeError("eval_cache_entries needs ONE evaluator (not evaluator={model_id: ...})")
-            sess.set_eval_cache(eval_cache_entries)
-        if evaluator is None:
-            p0 = np.array([r.player0_id for r in reqs], dtype=np.uint64)
-            p1 = np.array([r.player1_id for r in reqs], dtype=np.uint64)
-            ev = _CallbackEvaluator(sess, py_eval_pos_cb, max_nn_batch_size, lambda o: (p0[o], p1[o]))
-            steps = sess.run(ev, poll_every=1)
-        elif multi:
-            steps = sess.run(_MultiModelEvaluator(sess, evaluator))
-        else:
-            # a c4a0_amd.nn.InferenceNet is pure device code: replay it and the step kernel from a HIP graph
-            steps = sess.run(evaluator, steps_per_graph=(32 if len(reqs) >= 32 * n_slots else 8) if graph_safe else 0)
-        counts = sess.sample_counts()
-        recs = sess.drain_samples()
-        if stats is not None:
-            stats.update(sess.counters())
-            stats["steps"] = steps
-            stats["n_slots"] = n_slots
-            stats["rows_at_end"] = sess.rows
-            stats["concurrent_sessions"] = 1
-    finally:
-        sess.close()
-    return results_from_records(metas, recs, counts)
-
-
-def _play_concurrently(reqs, parts, n_slots, n_mcts_iterations, c_exploration, c_ply_penalty, evaluator, device,
-                       planes_dtype, blocks_per_slot, dirichlet, stats, eval_cache_entries=0):
-    """Session p plays requests p, p + parts, ...; records and counts come back in request order."""
-    from .session import SAMPLE_DTYPE, run_sessions
-
+    if eval_cache_entries and multi:
+        raise TypeError("eval_cache_entries needs ONE evaluator (not evaluator={model_id: ...})")
+    # longer graphs amortise the replay boundary (+2.5 % at 32); all but very long jobs keep the finer
+    # stop granularity (a 16 384-game job: 16.0 k games/s at 8 steps per graph, 14.9 k at 32)
+    steps_per_graph = (32 if len(reqs) >= 32 * n_slots else 8) if graph_safe else 0
     sessions = []
     try:
-        for p in range(parts):
+        for p in range(parts):   # session p plays requests p, p + parts, ...
             mine = reqs[p::parts]
             slots = min(len(mine), (n_slots + parts - 1 - p) // parts)
             s = DeviceSession(max(1, slots), n_mcts_iterations, c_exploration, c_ply_penalty, device=device,
                               planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot)
             sessions.append(s)
             s.set_games([(r.game_id, r.player0_id, r.player1_id) for r in mine])
-            if dirichlet is not None:
+            if dirichlet is not None:   # extension: (alpha, epsilon) root noise; the reference has none
                 s.set_dirichlet(*dirichlet)
-            if eval_cache_entries:   # each session keeps its own table (half the entries each)
+            if eval_cache_entries:      # extension: evaluation cache, each session keeps its own table
                 s.set_eval_cache(max(1024, int(eval_cache_entries) // parts))
-        # longer graphs amortise the replay boundary (+2.5 % at 32); all but very long jobs keep the finer
-        # stop granularity (a 16 384-game job: 16.0 k games/s at 8 steps per graph, 14.9 k at 32)
-        steps = run_sessions(sessions, evaluator, steps_per_graph=32 if len(reqs) >= 32 * n_slots else 8)
-        counts = np.zeros(len(reqs), dtype=np.uint32)
-        part_counts = [s.sample_counts() for s in sessions]
-        for p in range(parts):
-            counts[p::parts] = part_counts[p]
-        starts = np.concatenate([[0], np.cumsum(counts, dtype=np.int64)])      # first record of request i in the merged array
-        recs = np.zeros(int(starts[-1]), dtype=SAMPLE_DTYPE)
+        if parts > 1:
+            steps = max(run_sessions(sessions, evaluator, steps_per_graph=steps_per_graph))
+        elif evaluator is None:
+            p0 = np.array([r.player0_id for r in reqs], dtype=np.uint64)
+            p1 = np.array([r.player1_id for r in reqs], dtype=np.uint64)
+            ev = _CallbackEvaluator(sessions[0], py_eval_pos_cb, max_nn_batch_size, lambda o: (p0[o], p1[o]))
+            steps = sessions[0].run(ev, poll_every=1)
+        elif multi:
+            steps = sessions[0].run(_MultiModelEvaluator(sessions[0], evaluator))
+        else:
+            # a c4a0_amd.nn.InferenceNet is pure device code: replay it and the step kernel from a HIP graph
+            steps = sessions[0].run(evaluator, steps_per_graph=steps_per_graph)
+        pieces = []
         for p, s in enumerate(sessions):
-            r = s.drain_samples()
-            c = part_counts[p].astype(np.int64)
-            src0 = np.concatenate([[0], np.cumsum(c)])[:-1]
-            dst = np.repeat(starts[:-1][p::parts] - src0, c) + np.arange(len(r), dtype=np.int64)
-            recs[dst] = r
+            pos = np.arange(p, len(reqs), parts, dtype=np.int64)
+            pieces.append((pos, s.sample_counts(), s.pack_samples_device() if on_device else s.drain_samples()))
+        if parts == 1:
+            recs, counts = pieces[0][2], pieces[0][1]
+        else:
+            recs, counts = merge_parts(len(reqs), pieces)
         if stats is not None:
             tot = {}
             for s in sessions:
                 for k, v in s.counters().items():
                     tot[k] = tot.get(k, 0) + v if k not in ("error", "error_slot") else max(tot.get(k, 0), v)
             stats.update(tot)
-            stats["steps"] = max(steps)
+            stats["steps"] = steps
             stats["n_slots"] = sum(s.n_slots for s in sessions)
             stats["rows_at_end"] = sum(s.rows for s in sessions)
             stats["concurrent_sessions"] = parts
+            if evaluator is None:
+                stats["nn_positions"] = ev.nn_positions
     finally:
         for s in sessions:
             s.close()
     return recs, counts
+
+
+class DeviceCallback:
+    """A `py_eval_pos_cb`-shaped object for unmodified callers (training.py:179-189 builds
+    `lambda model_id, x: model.forward_numpy(x)`): calling it answers numpy batches exactly like the
+    reference callback, and `play_games` recognises `.device_evaluator` and plays in device mode, so the
+    leaf batches never leave HBM.  `evaluator` is a DeviceEvaluator or {model_id: DeviceEvaluator}."""
+
+    def __init__(self, evaluator, device=None):
+        self.device_evaluator = evaluator
+        self.device = device
+
+    def __call__(self, model_id: int, x: np.ndarray):
+        ev = self.device_evaluator[model_id] if isinstance(self.device_evaluator, dict) else self.device_evaluator
+        dev = self.device if self.device is not None else getattr(ev, "device", None)
+        with torch.no_grad():
+            lp, q = ev(torch.from_numpy(np.ascontiguousarray(x)).to(dev))
+            lp, q = lp.float().cpu().numpy(), q.float().cpu().numpy()
+        return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
 
 
 def run_tui(*_a, **_k):

@@ -27,9 +27,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 
 #include "../../include/c4a0_hip.h"
+#include "c4_host.hpp"
 
 namespace {
 
@@ -298,7 +302,30 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   }
 }
 
-thread_local std::string g_tower_error;
+// More than 64 KB of dynamic LDS needs an opt-in per kernel AND per device (hipFuncSetAttribute
+// acts on the current device's function object): remembered per (kernel, device).
+hipError_t opt_in_lds(const void* kernel, int bytes, int device) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, bool> done;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(kernel, device);
+  if (done.count(key)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done[key] = true;
+  return e;
+}
+
+template <int C, int NB, int NT, int A, int B>
+int launch_tower(const TowerParams& p, uint32_t n_boards, hipStream_t stream, int device) {
+  constexpr int kLds = Geo<C, NB>::kLdsBytes;
+  auto k = c4_conv_tower_kernel<C, NB, NT, A, B>;
+  hipError_t e = opt_in_lds((const void*)k, kLds, device);
+  if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: LDS opt-in (") + std::to_string(kLds) + " bytes) on device " + std::to_string(device) + ": " + hipGetErrorString(e));
+  k<<<dim3((n_boards + NB - 1) / NB), dim3(NT), kLds, stream>>>(p);
+  e = hipGetLastError();
+  if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16 launch: ") + hipGetErrorString(e));
+  return C4_OK;
+}
 
 }  // namespace
 
@@ -309,61 +336,26 @@ extern "C" {
 //   w_dev    bf16 [2*n_blocks][9][C/16][C/32][64][8] : lane l element j = W[co = 16 m + (l & 15)][ci = 32 kc + 8 (l >> 4) + j][tap]
 //   bias_dev f32  [1 + 2*n_blocks][C]
 //   out_dev  bf16 [n_boards][42][C]   (cell-major, channels last)
+// Runs on the device `stream` belongs to (the current device for the null stream).
 int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w_dev, const float* bias_dev,
                        uint32_t n_boards, uint32_t channels, uint32_t n_blocks, void* out_dev, void* stream) {
-  if (!planes_dev || !w0_dev || !bias_dev || !out_dev || (n_blocks && !w_dev)) return C4_ERR_BAD_ARG;
+  if (!planes_dev || !w0_dev || !bias_dev || !out_dev || (n_blocks && !w_dev)) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: null argument");
+  if (channels != 32 && channels != 64) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: channels must be 32 or 64");
   if (n_boards == 0) return C4_OK;
+  const int device = c4host::stream_device((hipStream_t)stream);
+  c4host::DeviceGuard guard(device);
+  if (guard.error() != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: hipSetDevice: ") + hipGetErrorString(guard.error()));
   TowerParams p{(const uint16_t*)planes_dev, (const bf16x8*)w0_dev, (const bf16x8*)w_dev, bias_dev, (uint16_t*)out_dev, n_boards, n_blocks};
-  hipError_t e = hipSuccess;
-  if (channels == 32 && n_boards <= 8 * 160) {
+  if (channels == 32 && n_boards <= 8 * 160)
     // small launches (up to 1 280 boards): 8 boards per workgroup, three tiles in flight per wave, so
     // that the launch spreads over twice as many CUs (2 048 boards alone: 31.6 -> 20.5 us).  NOT used for
     // the 2 048-board launches of two concurrent sessions: there the other session fills the rest of
     // the chip and what counts is CU-time per board, which is 30 % higher this way (measured: -1.7 %
     // games/s at BASELINE config 2).
-    constexpr int NB = 8;
-    constexpr int kLds = Geo<32, NB>::kLdsBytes;
-    auto k = c4_conv_tower_kernel<32, NB, 512, 3, 1>;
-    static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
-    if (!lds_opt_in) {
-      e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-      lds_opt_in = (e == hipSuccess);
-    }
-    if (e == hipSuccess) {
-      k<<<dim3((n_boards + NB - 1) / NB), dim3(512), kLds, (hipStream_t)stream>>>(p);
-      e = hipGetLastError();
-    }
-  } else if (channels == 32) {
-    constexpr int NB = 16;
-    constexpr int kLds = Geo<32, NB>::kLdsBytes;
-    auto k = c4_conv_tower_kernel<32, NB, 512, 2, 1>;   // 8 waves: two per SIMD, measured best (49 -> 32 us)
-    const int nt = 512;
-    static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
-    if (!lds_opt_in) {
-      e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-      lds_opt_in = (e == hipSuccess);
-    }
-    if (e == hipSuccess) {
-      k<<<dim3((n_boards + NB - 1) / NB), dim3(nt), kLds, (hipStream_t)stream>>>(p);
-      e = hipGetLastError();
-    }
-  } else if (channels == 64) {
-    constexpr int NB = 8;
-    constexpr int kLds = Geo<64, NB>::kLdsBytes;
-    auto k = c4_conv_tower_kernel<64, NB, 512, 1, 2>;   // 8 wavefronts: pairs split the output channels, two per SIMD
-    static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs a one-time opt-in per kernel
-    if (!lds_opt_in) {
-      e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-      lds_opt_in = (e == hipSuccess);
-    }
-    if (e == hipSuccess) {
-      k<<<dim3((n_boards + NB - 1) / NB), dim3(512), kLds, (hipStream_t)stream>>>(p);
-      e = hipGetLastError();
-    }
-  } else {
-    return C4_ERR_BAD_ARG;
-  }
-  return e == hipSuccess ? C4_OK : C4_ERR_HIP;
+    return launch_tower<32, 8, 512, 3, 1>(p, n_boards, (hipStream_t)stream, device);
+  if (channels == 32)
+    return launch_tower<32, 16, 512, 2, 1>(p, n_boards, (hipStream_t)stream, device);   // 8 waves: two per SIMD, measured best (49 -> 32 us)
+  return launch_tower<64, 8, 512, 1, 2>(p, n_boards, (hipStream_t)stream, device);      // 8 wavefronts: pairs split the output channels, two per SIMD
 }
 
 }  // extern "C"
@@ -526,18 +518,24 @@ extern "C" int c4_head_out_bf16(const void* hidden_policy_dev, const void* hidde
                                 uint32_t n_boards, uint32_t features, uint32_t policy_row_stride, uint32_t value_row_stride,
                                 float* logprobs_dev, float* q_dev, void* stream) {
   if (!hidden_policy_dev || !hidden_value_dev || !w_policy_dev || !w_value_dev || !b_policy_dev || !b_value_dev || !logprobs_dev || !q_dev)
-    return C4_ERR_BAD_ARG;
-  if (features % 8 != 0 || policy_row_stride % 8 != 0 || value_row_stride % 8 != 0) return C4_ERR_BAD_ARG;
+    return c4host::fail(C4_ERR_BAD_ARG, "c4_head_out_bf16: null argument");
+  if (features % 8 != 0 || policy_row_stride % 8 != 0 || value_row_stride % 8 != 0)
+    return c4host::fail(C4_ERR_BAD_ARG, "c4_head_out_bf16: features and row strides must be multiples of 8 elements");
   if (n_boards == 0) return C4_OK;
+  const int device = c4host::stream_device((hipStream_t)stream);
+  c4host::DeviceGuard guard(device);
+  if (guard.error() != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_head_out_bf16: hipSetDevice: ") + hipGetErrorString(guard.error()));
   if ((features / 8) % (4 * kHeadSteps * kHeadWaves) == 0) {
     c4_head_out_mfma_kernel<<<dim3((n_boards + 15) / 16), dim3(64 * kHeadWaves), 0, (hipStream_t)stream>>>(
         (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
         b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
-    return hipGetLastError() == hipSuccess ? C4_OK : C4_ERR_HIP;
+  } else {
+    constexpr int kBoardsPerWave = 2;   // other feature counts: dot-product form (measured best of 1 / 2 / 4 boards per wavefront)
+    c4_head_out_kernel<kBoardsPerWave><<<dim3((n_boards + 4 * kBoardsPerWave - 1) / (4 * kBoardsPerWave)), dim3(256), 0, (hipStream_t)stream>>>(
+        (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
+        b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
   }
-  constexpr int kBoardsPerWave = 2;   // other feature counts: dot-product form (measured best of 1 / 2 / 4 boards per wavefront)
-  c4_head_out_kernel<kBoardsPerWave><<<dim3((n_boards + 4 * kBoardsPerWave - 1) / (4 * kBoardsPerWave)), dim3(256), 0, (hipStream_t)stream>>>(
-      (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
-      b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
-  return hipGetLastError() == hipSuccess ? C4_OK : C4_ERR_HIP;
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_head_out_bf16 launch: ") + hipGetErrorString(e));
+  return C4_OK;
 }

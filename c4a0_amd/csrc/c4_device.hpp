@@ -198,7 +198,8 @@ C4_DEV void apply_temperature(const float* p, float t, float* out) {
 // ------------------------------------------------------------------------------------------
 // Move sampling (mcts.rs:214-222): StdRng::seed_from_u64 + WeightedIndex<f32>, i.e. rand 0.10.1 /
 // rand_core 0.10.1 (PCG32 seed expansion) / chacha20 0.10.1 (ChaCha12).  Restated from the
-// crates' documented algorithm (their source is not part of the reference checkout).
+// crates' documented algorithm (their source is not part of the reference checkout); the oracle
+// twin of each stage reproduces the crates' own published test vectors (tests/test_oracle_libm_rng.py).
 // ------------------------------------------------------------------------------------------
 C4_DEV uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
 

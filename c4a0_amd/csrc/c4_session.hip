@@ -32,6 +32,7 @@
 
 #include "../../include/c4a0_hip.h"
 #include "c4_device.hpp"
+#include "c4_host.hpp"
 
 #pragma clang fp contract(off)
 
@@ -843,6 +844,35 @@ __global__ __launch_bounds__(256) void k_compact_move(Params p, const CompactPla
   if (threadIdx.x == 0) { p.slots[src].status = kIdle; p.slots[src].ordinal = 0xFFFFFFFFu; }
 }
 
+// Exclusive prefix sum of the per-game sample counts = where each game's records start in the packed
+// array.  One 1024-thread workgroup walks the list with a running carry (n_games is a few 10^4..10^6).
+__global__ __launch_bounds__(1024) void k_sample_offsets(const uint32_t* counts, unsigned long long n_games,
+                                                         unsigned long long* offsets, unsigned long long* total) {
+  __shared__ unsigned long long wave_sum[16];
+  __shared__ unsigned long long carry;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (unsigned long long base = 0; base < n_games; base += 1024) {
+    const unsigned long long i = base + tid;
+    const unsigned long long v = i < n_games ? counts[i] : 0ull;
+    unsigned long long x = v;                                   // inclusive scan inside the wavefront
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long y = ((unsigned long long)__shfl_up((int)(x >> 32), off, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)x, off, 64);
+      if ((int)lane >= off) x += y;
+    }
+    if (lane == 63) wave_sum[wave] = x;
+    __syncthreads();
+    unsigned long long before = carry;                           // sums of the wavefronts before this one
+    for (uint32_t w = 0; w < wave; w++) before += wave_sum[w];
+    if (i < n_games) offsets[i] = before + x - v;
+    __syncthreads();
+    if (tid == 1023) carry = before + x;
+    __syncthreads();
+  }
+  if (tid == 0) *total = carry;
+}
+
 // K6: pack finished games' records contiguously (one wavefront per game, 4 records per pass)
 __global__ __launch_bounds__(64) void k_pack_samples(const c4_sample_rec* src, const uint32_t* counts,
                                                      const unsigned long long* offsets, uint64_t n_games, c4_sample_rec* dst) {
@@ -858,11 +888,7 @@ __global__ __launch_bounds__(64) void k_pack_samples(const c4_sample_rec* src, c
 // Host side
 // ------------------------------------------------------------------------------------------
 thread_local std::string g_last_error;
-
-int fail(int code, const std::string& msg) {
-  g_last_error = msg;
-  return code;
-}
+using c4host::fail;
 
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \
@@ -872,6 +898,16 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 }  // namespace
+
+int c4host::fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+// run the rest of the entry point on the session's device; the caller's current device is restored on return
+#define C4_ON_DEVICE(dev)                   \
+  c4host::DeviceGuard _device_guard(dev);   \
+  HIP_TRY(_device_guard.error())
 
 struct c4_session {
   c4_config cfg{};
@@ -895,11 +931,23 @@ struct c4_session {
   uint32_t probe_error = 0;
   CompactPlan* plan_dev = nullptr;   // tail compaction scratch
   uint2* pairs_dev = nullptr;
+  unsigned long long* offsets_dev = nullptr;   // pack_samples: [n_games] record offsets + [1] total, sized by set_games
+  unsigned long long* total_host = nullptr;    // pinned
 };
 
 extern "C" {
 
 const char* c4_last_error_string(void) { return g_last_error.c_str(); }
+
+#ifndef C4_SOURCE_HASH
+#define C4_SOURCE_HASH "unknown"
+#endif
+// content hash of the sources this library was compiled from (c4a0_amd/csrc/build.py); the marker
+// prefix lets the build script read it from the file's bytes without loading the library
+const char* c4_source_hash(void) {
+  static const char marked[] = "c4a0-src-hash:" C4_SOURCE_HASH;
+  return marked + 14;
+}
 
 int c4_device_count(int* out) {
   int n = 0;
@@ -909,20 +957,10 @@ int c4_device_count(int* out) {
   return C4_OK;
 }
 
-int c4_session_create(const c4_config* cfg, c4_session** out) {
-  if (!cfg || !out) return fail(C4_ERR_BAD_ARG, "null argument");
-  if (cfg->n_slots == 0) return fail(C4_ERR_BAD_ARG, "n_slots must be > 0");
-  if (cfg->planes_dtype > 1) return fail(C4_ERR_BAD_ARG, "planes_dtype must be 0 (f32) or 1 (bf16)");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(C4_ERR_NO_DEVICE, "no HIP device visible");
-  if (cfg->device < 0 || cfg->device >= ndev) return fail(C4_ERR_BAD_ARG, "device ordinal out of range");
-  HIP_TRY(hipSetDevice(cfg->device));
-  c4_session* s = new c4_session();
-  s->cfg = *cfg;
+static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   uint64_t bps = cfg->blocks_per_slot;
   if (bps == 0) bps = 43ull * (cfg->n_mcts_iterations ? cfg->n_mcts_iterations : 1) + 8;
   if (bps < 2) bps = 2;
-  if (cfg->blocks_per_slot > kMaxBlocksPerSlot) { delete s; return fail(C4_ERR_BAD_ARG, "blocks_per_slot is limited to 65535 (16-bit child links)"); }
   if (bps > kMaxBlocksPerSlot) bps = kMaxBlocksPerSlot;   // n_mcts_iterations > 1523: overflow is still detected per slot
   s->cfg.blocks_per_slot = (uint32_t)bps;
   const size_t n = cfg->n_slots;
@@ -944,12 +982,9 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
       (e = hipMalloc(&p.clock_acc, 2 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.phase, (size_t)s->n_waves * 16 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipHostMalloc(&s->probe_host, sizeof(Globals))) != hipSuccess ||
-      (e = hipEventCreateWithFlags(&s->probe_event, hipEventDisableTiming)) != hipSuccess) {
-    std::string msg = std::string("allocating session (") + std::to_string((n * bps * sizeof(Block)) >> 20) +
-                      " MiB of tree arena): " + hipGetErrorString(e);
-    c4_session_destroy(s);
-    return fail(C4_ERR_HIP, msg);
-  }
+      (e = hipEventCreateWithFlags(&s->probe_event, hipEventDisableTiming)) != hipSuccess)
+    return fail(C4_ERR_HIP, std::string("allocating session (") + std::to_string((n * bps * sizeof(Block)) >> 20) +
+                                " MiB of tree arena): " + hipGetErrorString(e));
   p.n_waves = s->n_waves;
   HIP_TRY(hipMemset(p.stamps, 0, (size_t)s->n_waves * 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(p.clock_acc, 0, 2 * sizeof(unsigned long long)));
@@ -958,17 +993,39 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
   HIP_TRY(hipMemset(p.glob, 0, sizeof(Globals)));
   HIP_TRY(hipMemset(p.wave_ctr, 0, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long)));
   memset(s->probe_host, 0, sizeof(Globals));
+  return C4_OK;
+}
+
+int c4_session_create(const c4_config* cfg, c4_session** out) {
+  if (!cfg || !out) return fail(C4_ERR_BAD_ARG, "null argument");
+  *out = nullptr;
+  if (cfg->n_slots == 0) return fail(C4_ERR_BAD_ARG, "n_slots must be > 0");
+  if (cfg->planes_dtype > 1) return fail(C4_ERR_BAD_ARG, "planes_dtype must be 0 (f32) or 1 (bf16)");
+  if (cfg->blocks_per_slot > kMaxBlocksPerSlot) return fail(C4_ERR_BAD_ARG, "blocks_per_slot is limited to 65535 (16-bit child links)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(C4_ERR_NO_DEVICE, "no HIP device visible");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(C4_ERR_BAD_ARG, "device ordinal out of range");
+  C4_ON_DEVICE(cfg->device);
+  c4_session* s = new c4_session();
+  s->cfg = *cfg;
+  const int rc = session_create_on_device(cfg, s);
+  if (rc != C4_OK) {   // every failure path releases what was allocated (the message survives destroy)
+    const std::string msg = g_last_error;
+    c4_session_destroy(s);
+    return fail(rc, msg);
+  }
   *out = s;
   return C4_OK;
 }
 
 int c4_session_destroy(c4_session* s) {
   if (!s) return C4_OK;
-  (void)hipSetDevice(s->cfg.device);
+  c4host::DeviceGuard guard(s->cfg.device);
   if (s->stream) (void)hipStreamSynchronize(s->stream); else (void)hipDeviceSynchronize();
   (void)hipFree(s->p.slots); (void)hipFree(s->p.blocks); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob); (void)hipFree(s->p.stamps); (void)hipFree(s->p.clock_acc); (void)hipFree(s->p.phase);
   (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts); (void)hipFree(s->p.cache);
-  (void)hipFree(s->plan_dev); (void)hipFree(s->pairs_dev);
+  (void)hipFree(s->plan_dev); (void)hipFree(s->pairs_dev); (void)hipFree(s->offsets_dev);
+  if (s->total_host) (void)hipHostFree(s->total_host);
   (void)hipFree(s->reqs_dev); (void)hipFree(s->start_mask_dev); (void)hipFree(s->start_value_dev);
   if (s->probe_host) (void)hipHostFree(s->probe_host);
   if (s->probe_event) (void)hipEventDestroy(s->probe_event);
@@ -981,13 +1038,15 @@ int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n
   if (!s || (!reqs && n_games)) return fail(C4_ERR_BAD_ARG, "null argument");
   if ((start_masks == nullptr) != (start_values == nullptr)) return fail(C4_ERR_BAD_ARG, "start_masks and start_values go together");
   if (n_games >= (1ull << 32) - 1) return fail(C4_ERR_BAD_ARG, "too many games for one session");
-  HIP_TRY(hipSetDevice(s->cfg.device));
+  C4_ON_DEVICE(s->cfg.device);
   HIP_TRY(hipStreamSynchronize(s->stream));
   (void)hipFree(s->reqs_dev); (void)hipFree(s->start_mask_dev); (void)hipFree(s->start_value_dev);
-  (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts);
+  (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts); (void)hipFree(s->offsets_dev);
   s->reqs_dev = nullptr; s->start_mask_dev = s->start_value_dev = nullptr;
-  s->p.samples = nullptr; s->p.sample_counts = nullptr;
+  s->p.samples = nullptr; s->p.sample_counts = nullptr; s->offsets_dev = nullptr;
   const size_t ng = n_games ? n_games : 1;
+  HIP_TRY(hipMalloc(&s->offsets_dev, (ng + 1) * sizeof(unsigned long long)));
+  if (!s->total_host) HIP_TRY(hipHostMalloc(&s->total_host, sizeof(unsigned long long)));
   HIP_TRY(hipMalloc(&s->reqs_dev, ng * sizeof(c4_game_metadata)));
   HIP_TRY(hipMalloc(&s->p.samples, ng * C4_MAX_SAMPLES_PER_GAME * sizeof(c4_sample_rec)));
   HIP_TRY(hipMalloc(&s->p.sample_counts, ng * sizeof(uint32_t)));
@@ -1049,7 +1108,7 @@ int c4_session_set_eval_cache(c4_session* s, uint64_t n_entries, uint32_t max_si
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
   if (n_entries && s->p.leaf_models) return fail(C4_ERR_BAD_ARG, "the evaluation cache holds ONE evaluator's outputs: not with multi-model games");
   if (n_entries > (1ull << 31)) return fail(C4_ERR_BAD_ARG, "at most 2^31 cache entries");
-  HIP_TRY(hipSetDevice(s->cfg.device));
+  C4_ON_DEVICE(s->cfg.device);
   HIP_TRY(hipStreamSynchronize(s->stream));
   (void)hipFree(s->p.cache);
   s->p.cache = nullptr;
@@ -1069,7 +1128,7 @@ int c4_session_set_eval_cache(c4_session* s, uint64_t n_entries, uint32_t max_si
 int c4_session_start(c4_session* s) {
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
   if (!s->bound || !s->have_games) return fail(C4_ERR_NOT_BOUND, "bind_io and set_games must precede start");
-  HIP_TRY(hipSetDevice(s->cfg.device));
+  C4_ON_DEVICE(s->cfg.device);
   if (s->cfg.planes_dtype == 0)
     hipLaunchKernelGGL(c4_start_kernel<float>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
   else
@@ -1081,6 +1140,7 @@ int c4_session_start(c4_session* s) {
 int c4_session_step(c4_session* s) {
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
   if (!s->bound || !s->have_games) return fail(C4_ERR_NOT_BOUND, "bind_io and set_games must precede step");
+  C4_ON_DEVICE(s->cfg.device);
   // launch sequence number for the device-clock stamps; frozen at 0 (= no per-launch timing) when
   // timing is off, which is what a launch captured into a HIP graph needs (arguments are baked in)
   s->p.seq = s->timing ? ++s->seq : 0;
@@ -1101,7 +1161,7 @@ int c4_session_step(c4_session* s) {
 
 int c4_session_set_timing(c4_session* s, int enable) {
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
-  HIP_TRY(hipSetDevice(s->cfg.device));
+  C4_ON_DEVICE(s->cfg.device);
   HIP_TRY(hipStreamSynchronize(s->stream));
   // fold nothing across the switch: restart the stamp buffers
   HIP_TRY(hipMemset(s->p.stamps, 0, (size_t)s->n_waves_cap * 4 * sizeof(unsigned long long)));
@@ -1112,7 +1172,7 @@ int c4_session_set_timing(c4_session* s, int enable) {
 
 int c4_session_counters(c4_session* s, c4_counters* out) {
   if (!s || !out) return fail(C4_ERR_BAD_ARG, "null argument");
-  HIP_TRY(hipSetDevice(s->cfg.device));
+  C4_ON_DEVICE(s->cfg.device);
   HIP_TRY(hipStreamSynchronize(s->stream));
   std::vector<unsigned long long> h((size_t)s->n_waves_cap * CTR_N);   // waves retired by a compaction keep their counts
   HIP_TRY(hipMemcpy(h.data(), s->p.wave_ctr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1146,6 +1206,7 @@ int c4_session_counters(c4_session* s, c4_counters* out) {
 
 int c4_session_poll(c4_session* s, uint64_t* games_done, uint32_t* error) {
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  C4_ON_DEVICE(s->cfg.device);
   if (s->probe_pending && hipEventQuery(s->probe_event) == hipSuccess) {
     s->probe_done = s->probe_host->games_done;
     s->probe_started = s->probe_host->queue_head < s->n_games ? s->probe_host->queue_head : s->n_games;
@@ -1172,7 +1233,7 @@ int c4_session_compact(c4_session* s, uint32_t multiple, uint32_t* n_active, uin
   if (!s || !s->bound || !s->have_games) return fail(C4_ERR_BAD_ARG, "compact needs a bound session with games");
   if (s->p.leaf_models) return fail(C4_ERR_BAD_ARG, "compaction does not move the per-slot model ids of multi-model sessions");
   if (multiple == 0 || multiple % 8) return fail(C4_ERR_BAD_ARG, "multiple must be a positive multiple of 8");
-  HIP_TRY(hipSetDevice(s->cfg.device));
+  C4_ON_DEVICE(s->cfg.device);
   HIP_TRY(hipStreamSynchronize(s->stream));
   Globals g{};
   HIP_TRY(hipMemcpy(&g, s->p.glob, sizeof g, hipMemcpyDeviceToHost));
@@ -1209,7 +1270,7 @@ int c4_session_compact(c4_session* s, uint32_t multiple, uint32_t* n_active, uin
 int c4_session_sample_counts(c4_session* s, uint32_t* counts_host, uint64_t n_games) {
   if (!s || !counts_host) return fail(C4_ERR_BAD_ARG, "null argument");
   if (n_games != s->n_games) return fail(C4_ERR_BAD_ARG, "n_games does not match set_games");
-  HIP_TRY(hipSetDevice(s->cfg.device));
+  C4_ON_DEVICE(s->cfg.device);
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (n_games) HIP_TRY(hipMemcpy(counts_host, s->p.sample_counts, n_games * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return C4_OK;
@@ -1217,7 +1278,7 @@ int c4_session_sample_counts(c4_session* s, uint32_t* counts_host, uint64_t n_ga
 
 int c4_session_drain_samples(c4_session* s, c4_sample_rec* dst_host, uint64_t cap, uint64_t* n_written) {
   if (!s || !n_written) return fail(C4_ERR_BAD_ARG, "null argument");
-  HIP_TRY(hipSetDevice(s->cfg.device));
+  C4_ON_DEVICE(s->cfg.device);
   HIP_TRY(hipStreamSynchronize(s->stream));
   std::vector<uint32_t> counts(s->n_games ? s->n_games : 1);
   if (s->n_games) HIP_TRY(hipMemcpy(counts.data(), s->p.sample_counts, s->n_games * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1245,27 +1306,23 @@ int c4_session_drain_samples(c4_session* s, c4_sample_rec* dst_host, uint64_t ca
 
 int c4_session_pack_samples(c4_session* s, c4_sample_rec* dst_dev, uint64_t cap, uint64_t* n_written) {
   if (!s || !n_written) return fail(C4_ERR_BAD_ARG, "null argument");
-  HIP_TRY(hipSetDevice(s->cfg.device));
+  if (!s->have_games) return fail(C4_ERR_NOT_BOUND, "set_games must precede pack_samples");
+  C4_ON_DEVICE(s->cfg.device);
+  // record offsets by a device prefix sum into the session's persistent buffer; only the total comes back
+  unsigned long long* total_dev = s->offsets_dev + (s->n_games ? s->n_games : 1);
+  hipLaunchKernelGGL(k_sample_offsets, dim3(1), dim3(1024), 0, s->stream, s->p.sample_counts, (unsigned long long)s->n_games,
+                     s->offsets_dev, total_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->total_host, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  std::vector<uint32_t> counts(s->n_games ? s->n_games : 1);
-  if (s->n_games) HIP_TRY(hipMemcpy(counts.data(), s->p.sample_counts, s->n_games * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  std::vector<unsigned long long> offs(s->n_games ? s->n_games : 1);
-  uint64_t total = 0;
-  for (uint64_t i = 0; i < s->n_games; i++) { offs[i] = total; total += counts[i]; }
+  const uint64_t total = *s->total_host;
   *n_written = total;
   if (!dst_dev || total == 0) return C4_OK;  // size query
   if (cap < total) return fail(C4_ERR_BAD_ARG, "destination too small");
-  unsigned long long* offs_dev = nullptr;
-  HIP_TRY(hipMalloc(&offs_dev, s->n_games * sizeof(unsigned long long)));
-  hipError_t e = hipMemcpy(offs_dev, offs.data(), s->n_games * sizeof(unsigned long long), hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)s->n_games), dim3(64), 0, s->stream, s->p.samples, s->p.sample_counts,
-                       offs_dev, s->n_games, dst_dev);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-  }
-  (void)hipFree(offs_dev);
-  if (e != hipSuccess) return fail(C4_ERR_HIP, std::string("pack_samples: ") + hipGetErrorString(e));
+  hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)s->n_games), dim3(64), 0, s->stream, s->p.samples, s->p.sample_counts,
+                     s->offsets_dev, s->n_games, dst_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s->stream));
   return C4_OK;
 }
 
@@ -1291,7 +1348,7 @@ int c4_session_sample_store(c4_session* s, const c4_sample_rec** recs_dev, const
 int c4_session_root_stats(c4_session* s, uint32_t slot, float policy[7], float* q_penalty, float* q_no_penalty,
                           uint64_t* visit_count, uint64_t* root_mask, uint64_t* root_value) {
   if (!s || slot >= s->cfg.n_slots) return fail(C4_ERR_BAD_ARG, "bad slot");
-  HIP_TRY(hipSetDevice(s->cfg.device));
+  C4_ON_DEVICE(s->cfg.device);
   HIP_TRY(hipStreamSynchronize(s->stream));
   Slot st;
   HIP_TRY(hipMemcpy(&st, s->p.slots + slot, sizeof st, hipMemcpyDeviceToHost));
@@ -1323,7 +1380,7 @@ int c4_session_root_stats(c4_session* s, uint32_t slot, float policy[7], float* 
 int c4_session_leaves(c4_session* s, uint64_t* masks_host, uint64_t* values_host, uint32_t* status_host,
                       uint32_t* ordinals_host) {
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
-  HIP_TRY(hipSetDevice(s->cfg.device));
+  C4_ON_DEVICE(s->cfg.device);
   HIP_TRY(hipStreamSynchronize(s->stream));
   std::vector<Slot> h(s->cfg.n_slots);
   HIP_TRY(hipMemcpy(h.data(), s->p.slots, h.size() * sizeof(Slot), hipMemcpyDeviceToHost));

@@ -4,11 +4,15 @@ no traffic while playing, ONE variable-length all-gather of the finished samples
 Games never interact (reference rust/src/self_play.rs:55-58: one MctsGame per GameMetadata)
 and the move RNG is a pure function of (game_id, n_moves) (mcts.rs:215), so a game's samples
 do not depend on which rank plays it.  `torch.distributed` backend "nccl" is RCCL on ROCm
-(xGMI between the 8 GPUs of a node); the same code runs over "gloo" on CPU tensors in the tests.
+(xGMI between the 8 GPUs of a node); the same code runs over "gloo" (records staged through the
+host) in the tests.
+
+    play_games_sharded(reqs, ...)   the product entry point: shard -> play -> pack -> gather -> merge
+    shard_indices / gather_shards / merge_shards   its pieces
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -22,6 +26,11 @@ def shard_indices(n_games: int, rank: int, world_size: int) -> np.ndarray:
     return np.arange(rank, n_games, world_size, dtype=np.int64)
 
 
+def _collective_device(local: torch.Tensor, group=None) -> torch.device:
+    """gloo moves host memory: stage through the CPU; RCCL ("nccl") takes the device tensor."""
+    return torch.device("cpu") if dist.get_backend(group) == "gloo" else local.device
+
+
 def all_gather_records(local: torch.Tensor, group=None) -> List[torch.Tensor]:
     """All-gather a per-rank uint8[n_r, 64] record tensor of varying n_r.
 
@@ -30,38 +39,107 @@ def all_gather_records(local: torch.Tensor, group=None) -> List[torch.Tensor]:
     shard moves as one message per peer link (payload ~1.1 KB per game)."""
     assert local.dtype == torch.uint8 and local.dim() == 2 and local.shape[1] == SAMPLE_BYTES
     world = dist.get_world_size(group)
-    dev = local.device
+    dev = _collective_device(local, group)
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)
     counts = [int(c.item()) for c in counts]
-    cap = max(1, max(counts))
+    return _all_gather_padded(local, counts, group)
+
+
+def _all_gather_padded(local: torch.Tensor, n_per_rank: Sequence[int], group=None) -> List[torch.Tensor]:
+    world = dist.get_world_size(group)
+    dev = _collective_device(local, group)
+    cap = max(1, max(n_per_rank))
     padded = torch.zeros((cap, SAMPLE_BYTES), dtype=torch.uint8, device=dev)
-    padded[: local.shape[0]] = local
+    padded[: local.shape[0]] = local.to(dev)
     bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded, group=group)
-    return [b[:c] for b, c in zip(bufs, counts)]
+    return [b[:c] for b, c in zip(bufs, n_per_rank)]
+
+
+def gather_shards(local_records: torch.Tensor, local_counts: np.ndarray, n_games: int, group=None
+                  ) -> Tuple[List[torch.Tensor], List[np.ndarray]]:
+    """The path's one exchange step.  `local_records` uint8[n_r, 64] = this rank's packed records in
+    the order of its shard (`shard_indices`), `local_counts` the per-game sample counts of that shard.
+    Two fixed-size collectives: the per-game counts (every rank knows the shard sizes, so no size
+    exchange), then the records padded to the largest shard's record count (known from the counts).
+    Returns (records per rank, counts per rank) on every rank."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = _collective_device(local_records, group)
+    cap_games = max(1, (n_games + world - 1) // world)
+    mine = torch.zeros(cap_games, dtype=torch.int32, device=dev)
+    mine[: len(local_counts)] = torch.as_tensor(np.asarray(local_counts).astype(np.int32), device=dev)
+    all_counts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(all_counts, mine, group=group)
+    counts = [c.cpu().numpy().astype(np.uint32)[: len(shard_indices(n_games, r, world))] for r, c in enumerate(all_counts)]
+    n_per_rank = [int(c.sum()) for c in counts]
+    if n_per_rank[rank] != local_records.shape[0]:
+        raise ValueError(f"rank {rank}: {local_records.shape[0]} packed records but the counts add up to {n_per_rank[rank]}")
+    return _all_gather_padded(local_records, n_per_rank, group), counts
+
+
+def merge_shards(per_rank_records: Sequence, per_rank_counts: Sequence[np.ndarray], n_games: int):
+    """Interleave the ranks' packed records back into request-list order (vectorised; numpy
+    SAMPLE_DTYPE arrays or torch uint8[n, 64] tensors).  Returns (records, counts[n_games])."""
+    from .api import merge_parts
+
+    world = len(per_rank_records)
+    return merge_parts(n_games, [(shard_indices(n_games, r, world), per_rank_counts[r], per_rank_records[r]) for r in range(world)])
 
 
 def merge_rank_records(per_rank: Sequence[np.ndarray], n_games: int, world_size: int, counts_per_rank: Sequence[np.ndarray]):
-    """Interleave the ranks' packed records back into request-list order.
+    """Round-1 name of `merge_shards` (numpy records)."""
+    return merge_shards([per_rank[r] for r in range(world_size)],
+                        [np.asarray(counts_per_rank[r])[: len(shard_indices(n_games, r, world_size))] for r in range(world_size)], n_games)
 
-    per_rank[r] holds the records of games r, r+W, r+2W, ... packed in that order and
-    counts_per_rank[r][k] the sample count of game r + k*W.  Returns (records, counts)."""
+
+def play_games_sharded(reqs, max_nn_batch_size: int, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float,
+                       *, evaluator, group=None, device=None, stats: Optional[dict] = None, **play_kwargs):
+    """`play_games` over all ranks of an initialised process group (one process per GPU).
+
+    Every rank passes the SAME `reqs`; rank r plays request positions r, r + W, ... in device mode on
+    its own GPU with its own replica of `evaluator` (no traffic while games are played), packs its
+    finished records on the device (k_pack_samples), takes part in the count + padded-record
+    all-gathers (`gather_shards`; RCCL over xGMI with backend "nccl", host-staged with "gloo") and
+    merges all shards: every rank returns the full `PlayGamesResult` in request order, identical to
+    what a single process playing all of `reqs` returns.  `play_kwargs` are `play_games`' keywords
+    (resident_games, concurrent_sessions, dirichlet, ...).  `stats` receives this rank's counters plus
+    the exchange's wall time and byte count."""
+    import time
+
+    from .api import _play, _validate
+    from .results import GameMetadata, PlayGamesResult, results_from_records
     from .session import SAMPLE_DTYPE
 
-    counts = np.zeros(n_games, dtype=np.uint32)
-    for r in range(world_size):
-        idx = shard_indices(n_games, r, world_size)
-        counts[idx] = counts_per_rank[r][: idx.size]
-    offs = np.concatenate([[0], np.cumsum(counts, dtype=np.int64)])
-    out = np.zeros(int(offs[-1]), dtype=SAMPLE_DTYPE)
-    for r in range(world_size):
-        idx = shard_indices(n_games, r, world_size)
-        recs = per_rank[r]
-        o = 0
-        for g in idx:
-            c = int(counts[g])
-            out[offs[g]:offs[g] + c] = recs[o:o + c]
-            o += c
-    return out, counts
+    if not dist.is_initialized():
+        raise RuntimeError("play_games_sharded needs torch.distributed.init_process_group() first")
+    reqs = list(reqs)
+    _validate(reqs, max_nn_batch_size, n_mcts_iterations, None, evaluator)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = len(reqs)
+    if n == 0:
+        return PlayGamesResult([])
+    mine = [reqs[i] for i in shard_indices(n, rank, world)]
+    kw = dict(device=device, resident_games=None, planes_dtype=None, blocks_per_slot=0, dirichlet=None,
+              concurrent_sessions=None, eval_cache_entries=0)
+    unknown = set(play_kwargs) - set(kw)
+    if unknown:
+        raise TypeError(f"unknown play_games keywords {sorted(unknown)}")
+    kw.update(play_kwargs)
+    if mine:
+        recs_dev, counts = _play(mine, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, None, evaluator,
+                                 kw["device"], kw["resident_games"], kw["planes_dtype"], kw["blocks_per_slot"], stats, kw["dirichlet"],
+                                 kw["concurrent_sessions"], kw["eval_cache_entries"], on_device=True)
+    else:   # more ranks than games
+        dev = torch.device(kw["device"]) if kw["device"] is not None else torch.device("cuda", torch.cuda.current_device())
+        recs_dev, counts = torch.zeros((0, SAMPLE_BYTES), dtype=torch.uint8, device=dev), np.zeros(0, dtype=np.uint32)
+    t0 = time.perf_counter()
+    per_rank, per_counts = gather_shards(recs_dev, counts, n, group)
+    merged, all_counts = merge_shards(per_rank, per_counts, n)          # torch ops on the collective's device
+    recs = merged.cpu().numpy().reshape(-1).view(SAMPLE_DTYPE)
+    if stats is not None:
+        stats["sample_allgather"] = {"ms": (time.perf_counter() - t0) * 1e3, "records_per_rank": [int(p.shape[0]) for p in per_rank],
+                                     "bytes_total": int(sum(p.numel() for p in per_rank)), "backend": dist.get_backend(group)}
+    metas = [GameMetadata(r.game_id, r.player0_id, r.player1_id) for r in reqs]
+    return results_from_records(metas, recs, all_counts)

@@ -11,6 +11,8 @@ from __future__ import annotations
 import struct
 from typing import Iterable, List, Sequence, Tuple
 
+import math
+
 import numpy as np
 
 N_COLS, N_ROWS = 7, 6
@@ -265,6 +267,24 @@ class PlayGamesResult:
         self._lazy = None
         self._results = list(value)
 
+    def to_records(self):
+        """(records, counts): the packed 64-byte sample records (c4a0_amd.session.SAMPLE_DTYPE) in result
+        order and the number of samples of every game -- the form the GPU hands over (extension)."""
+        if self._lazy is not None:
+            _reqs, recs, counts = self._lazy
+            return recs, np.asarray(counts).astype(np.uint32)
+        from .session import SAMPLE_DTYPE
+
+        counts = np.array([len(r.samples) for r in self._results], dtype=np.uint32)
+        recs = np.zeros(int(counts.sum()), dtype=SAMPLE_DTYPE)
+        k = 0
+        for r in self._results:
+            for i, s in enumerate(r.samples):
+                recs[k] = (r.metadata.game_id, s.mask, s.value, np.asarray(s.policy, dtype=np.float32), s.q_penalty, s.q_no_penalty,
+                           i | ((1 << 16) if i == len(r.samples) - 1 else 0))
+                k += 1
+        return recs, counts
+
     def to_arrays(self):
         """Bulk view for training code (extension; the reference only has per-sample `to_numpy`):
         (planes float32[N,2,6,7], policy float32[N,7], q_penalty float32[N], q_no_penalty float32[N],
@@ -356,7 +376,10 @@ class PlayGamesResult:
     def split_train_test(self, train_frac: float, seed: int) -> Tuple[List[Sample], List[Sample]]:
         results = list(self.results)
         np.random.Generator(np.random.PCG64(int(seed) & ((1 << 64) - 1))).shuffle(results)
-        n_train = int(np.round(np.float32(len(results)) * np.float32(train_frac)))  # f32 math + round, as the reference
+        # (len as f32 * train_frac).round(): f32 product, then Rust's f32::round = half AWAY from zero
+        # (np.round is half-to-even: 5 games at 0.5 must give 3, not 2)
+        prod = float(np.float32(len(results)) * np.float32(train_frac))
+        n_train = int(math.floor(prod + 0.5)) if prod >= 0.0 else -int(math.floor(-prod + 0.5))
         n_train = max(0, min(len(results), n_train))
         train = [s for r in results[:n_train] for s in r.samples]
         test = [s for r in results[n_train:] for s in r.samples]

@@ -103,6 +103,9 @@ typedef struct {
 typedef struct c4_session c4_session;
 
 const char* c4_last_error_string(void);
+/* Content hash of the sources the library was compiled from (no reference counterpart: build
+ * hygiene; c4a0_amd/csrc/build.py rebuilds, and c4a0_amd/_lib.py refuses, a stale library). */
+const char* c4_source_hash(void);
 int c4_device_count(int* out);
 
 /* Replaces the set-up half of self_play() (self_play.rs:47-58): allocates the tree arenas,

@@ -351,7 +351,8 @@ void c4o_apply_temperature(const float* policy, float t, float* out) {
 /* ------------------------------------------------------------------------------------------
  * RNG -- third-party crates rand 0.10.1, rand_core 0.10.1, chacha20 0.10.1
  * (rust/Cargo.lock:1585-1593, 1621-1622, 269-277).  Source not in /root/reference:
- * restated from the crates' published algorithm.  PARITY UNPINNED (see header).
+ * restated from the crates' published algorithm and pinned stage by stage by the crates' own
+ * published unit-test vectors (see the header; tests/test_oracle_libm_rng.py).
  * Call site: mcts.rs:214-222.
  * ---------------------------------------------------------------------------------------- */
 
@@ -1097,5 +1098,255 @@ int c4o_self_play(const c4o_game_metadata* reqs, uint64_t n_games, int max_nn_ba
 
   free(games); free(n_out); free(tmp_samples); free(pending); free(tab); free(game_uid);
   free(umodel); free(upos); free(ubatch); free(planes); free(lp); free(qp); free(qn); free(status);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * self_play in the REFERENCE'S THREAD TOPOLOGY -- rust/src/self_play.rs:39-129: one NN thread
+ * (NNThread, :196-237) and n_threads - 1 MCTS worker threads (MctsThread, :268-323) exchanging
+ * games over two queues (crossbeam channels there, mutex + condvar rings here), so that network
+ * evaluation and tree work overlap exactly as in the reference.  The NN thread is the CALLING
+ * thread (the evaluator may be a Python callback).  Every game's samples equal c4o_self_play's:
+ * only the batching differs, and a game's trajectory depends on the answers for its own leaves
+ * alone.  Used by bench.py's cpu_baseline leg and checked against c4o_self_play in the tests.
+ * ---------------------------------------------------------------------------------------- */
+#include <pthread.h>
+
+typedef struct {
+  uint64_t game;      /* index into games[]; UINT64_MAX = MctsJob::PoisonPill (self_play.rs:317-322) */
+  float lp[7], qp, qn;
+} c4o_job;
+
+typedef struct {
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  /* nn_queue: games waiting for the network (self_play.rs:51) */
+  uint64_t* nn_items; uint64_t nn_head, nn_tail, nn_cap; int nn_closed;
+  /* mcts_queue: evaluated games waiting for a worker (self_play.rs:52) */
+  c4o_job* jobs; uint64_t job_head, job_tail, job_cap;
+  pthread_mutex_t jmu;
+  pthread_cond_t jcv;
+  /* shared state */
+  c4o_game** games; int* n_out; c4o_sample* tmp_samples;
+  uint64_t n_remaining; int n_workers; int error;
+  uint64_t n_iter; float c_exploration, c_ply_penalty;
+} c4o_async;
+
+static void async_push_nn(c4o_async* a, uint64_t gi) {
+  pthread_mutex_lock(&a->mu);
+  a->nn_items[a->nn_tail++ % a->nn_cap] = gi;
+  pthread_cond_signal(&a->cv);
+  pthread_mutex_unlock(&a->mu);
+}
+
+static void async_push_jobs(c4o_async* a, const c4o_job* j, uint64_t n) {
+  pthread_mutex_lock(&a->jmu);
+  for (uint64_t i = 0; i < n; i++) a->jobs[a->job_tail++ % a->job_cap] = j[i];
+  if (n == 1) pthread_cond_signal(&a->jcv); else pthread_cond_broadcast(&a->jcv);
+  pthread_mutex_unlock(&a->jmu);
+}
+
+/* MctsThread::loop_until_close (self_play.rs:268-323) */
+static void* async_worker(void* arg) {
+  c4o_async* a = (c4o_async*)arg;
+  for (;;) {
+    c4o_job j;
+    pthread_mutex_lock(&a->jmu);
+    while (a->job_head == a->job_tail) pthread_cond_wait(&a->jcv, &a->jmu);
+    j = a->jobs[a->job_head++ % a->job_cap];
+    pthread_mutex_unlock(&a->jmu);
+    if (j.game == UINT64_MAX) break;
+    c4o_game* g = a->games[j.game];
+    int st = c4o_game_step(g, j.lp, j.qp, j.qn, a->n_iter, a->c_exploration, a->c_ply_penalty);
+    if (st == 0) { async_push_nn(a, j.game); continue; }
+    if (st == 1) {
+      a->n_out[j.game] = c4o_game_to_result(g, a->c_ply_penalty, a->tmp_samples + 43 * j.game, 43);
+      c4o_counters c;
+      c4o_game_counters(g, &c);
+      free(g->nodes);
+      g->nodes = NULL;
+      g->n_nodes = g->cap = 0;
+      g->ctr = c;
+    } else {
+      __atomic_store_n(&a->error, -st, __ATOMIC_RELAXED);
+    }
+    /* game over (or failed): the thread that retires the last game poisons the others and lets the
+     * NN thread see its queue close (self_play.rs:302-312, 30-38) */
+    if (__atomic_sub_fetch(&a->n_remaining, 1, __ATOMIC_ACQ_REL) == 0) {
+      c4o_job pill;
+      memset(&pill, 0, sizeof pill);
+      pill.game = UINT64_MAX;
+      for (int w = 0; w < a->n_workers - 1; w++) async_push_jobs(a, &pill, 1);
+      pthread_mutex_lock(&a->mu);
+      a->nn_closed = 1;
+      pthread_cond_signal(&a->cv);
+      pthread_mutex_unlock(&a->mu);
+      break;
+    }
+  }
+  return NULL;
+}
+
+int c4o_self_play_async(const c4o_game_metadata* reqs, uint64_t n_games, int max_nn_batch_size,
+                        uint64_t n_mcts_iterations, float c_exploration, float c_ply_penalty,
+                        c4o_eval_fn eval, void* eval_ctx, int n_threads,
+                        c4o_sample* out_samples, uint64_t* out_offsets, c4o_selfplay_stats* stats) {
+  if (max_nn_batch_size < 1) max_nn_batch_size = 1;
+  if (n_threads < 2) n_threads = 2; /* the NN thread + at least one worker (self_play.rs:78) */
+  c4o_selfplay_stats st;
+  memset(&st, 0, sizeof st);
+  st.n_games = n_games;
+  const size_t ng = n_games ? n_games : 1;
+  c4o_async a;
+  memset(&a, 0, sizeof a);
+  pthread_mutex_init(&a.mu, NULL); pthread_cond_init(&a.cv, NULL);
+  pthread_mutex_init(&a.jmu, NULL); pthread_cond_init(&a.jcv, NULL);
+  a.n_workers = n_threads - 1;
+  a.nn_cap = ng; a.nn_items = (uint64_t*)malloc(sizeof(uint64_t) * ng);
+  a.job_cap = ng + (size_t)n_threads; a.jobs = (c4o_job*)malloc(sizeof(c4o_job) * a.job_cap);
+  a.games = (c4o_game**)calloc(ng, sizeof(c4o_game*));
+  a.n_out = (int*)calloc(ng, sizeof(int));
+  a.tmp_samples = (c4o_sample*)malloc(sizeof(c4o_sample) * 43 * ng);
+  a.n_remaining = n_games;
+  a.n_iter = n_mcts_iterations; a.c_exploration = c_exploration; a.c_ply_penalty = c_ply_penalty;
+  c4o_pos start = {0, 0};
+  for (uint64_t i = 0; i < n_games; i++) {
+    a.games[i] = c4o_game_new(&start, reqs[i].game_id, reqs[i].player0_id, reqs[i].player1_id);
+    c4o_game_set_dirichlet(a.games[i], g_sp_dir_alpha, g_sp_dir_eps);
+    a.nn_items[a.nn_tail++] = i; /* self_play.rs:55-58 */
+  }
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)a.n_workers);
+  int started = 0;
+  if (n_games > 0)
+    for (; started < a.n_workers; started++)
+      if (pthread_create(&th[started], NULL, async_worker, &a) != 0) break;
+  int rc = (n_games > 0 && started < a.n_workers) ? C4O_ERR_ILLEGAL_MOVE : C4O_OK;
+
+  /* NNThread::loop_until_close (self_play.rs:196-237) on the calling thread */
+  uint64_t* pend = (uint64_t*)malloc(sizeof(uint64_t) * ng);
+  uint64_t n_pend = 0;
+  size_t tab_cap = 16;
+  while (tab_cap < 2 * ng + 2) tab_cap *= 2;
+  c4o_slot* tab = (c4o_slot*)malloc(sizeof(c4o_slot) * tab_cap);
+  int* game_uid = (int*)malloc(sizeof(int) * ng);
+  uint64_t* umodel = (uint64_t*)malloc(sizeof(uint64_t) * ng);
+  c4o_pos* upos = (c4o_pos*)malloc(sizeof(c4o_pos) * ng);
+  int* ubatch = (int*)malloc(sizeof(int) * ng);
+  float* planes = (float*)malloc(sizeof(float) * 84 * (size_t)max_nn_batch_size);
+  float* lp = (float*)malloc(sizeof(float) * 7 * (size_t)max_nn_batch_size);
+  float* qp = (float*)malloc(sizeof(float) * (size_t)max_nn_batch_size);
+  float* qn = (float*)malloc(sizeof(float) * (size_t)max_nn_batch_size);
+  c4o_job* out_jobs = (c4o_job*)malloc(sizeof(c4o_job) * ng);
+  int closed = 0;
+  while (rc == C4O_OK && n_games > 0 && (!closed || n_pend > 0)) {
+    /* drain_queue: block while nothing is pending, then take everything that is there */
+    pthread_mutex_lock(&a.mu);
+    while (n_pend == 0 && a.nn_head == a.nn_tail && !a.nn_closed) pthread_cond_wait(&a.cv, &a.mu);
+    while (a.nn_head != a.nn_tail) pend[n_pend++] = a.nn_items[a.nn_head++ % a.nn_cap];
+    closed = a.nn_closed;
+    pthread_mutex_unlock(&a.mu);
+    if (__atomic_load_n(&a.error, __ATOMIC_RELAXED)) break;
+    if (n_pend == 0) continue;
+    /* unique (model, leaf position) pairs of the pending games */
+    memset(tab, 0, sizeof(c4o_slot) * tab_cap);
+    int n_unique = 0;
+    for (uint64_t k = 0; k < n_pend; k++) {
+      uint64_t gi = pend[k];
+      uint64_t model = c4o_game_leaf_model_id(a.games[gi]);
+      c4o_pos lpz;
+      c4o_game_leaf_pos(a.games[gi], &lpz);
+      size_t h = (size_t)(mix64(lpz.mask * 0x9E3779B97F4A7C15ull ^ mix64(lpz.value ^ model * 0xD6E8FEB86659FD93ull))) & (tab_cap - 1);
+      for (;;) {
+        if (!tab[h].used) {
+          tab[h].used = 1; tab[h].model = model; tab[h].pos = lpz; tab[h].uid = n_unique;
+          umodel[n_unique] = model; upos[n_unique] = lpz;
+          n_unique++;
+          break;
+        }
+        if (tab[h].model == model && tab[h].pos.mask == lpz.mask && tab[h].pos.value == lpz.value) break;
+        h = (h + 1) & (tab_cap - 1);
+      }
+      game_uid[gi] = tab[h].uid;
+    }
+    /* the model with the most unique positions, ties to the largest id (self_play.rs:211-215) */
+    uint64_t best_model = 0, best_count = 0;
+    {
+      uint64_t mids[64], mcnt[64];
+      int n_models = 0, overflow = 0, have = 0;
+      for (int u = 0; u < n_unique; u++) {
+        int w = 0;
+        while (w < n_models && mids[w] != umodel[u]) w++;
+        if (w == n_models) {
+          if (n_models == 64) { overflow = 1; break; }
+          mids[n_models] = umodel[u]; mcnt[n_models] = 0; n_models++;
+        }
+        mcnt[w]++;
+      }
+      if (overflow) { rc = C4O_ERR_ILLEGAL_MOVE; break; }
+      for (int w = 0; w < n_models; w++)
+        if (!have || mcnt[w] > best_count || (mcnt[w] == best_count && mids[w] > best_model)) {
+          best_model = mids[w]; best_count = mcnt[w]; have = 1;
+        }
+    }
+    int nb = 0;
+    for (int u = 0; u < n_unique; u++) {
+      if (umodel[u] == best_model && nb < max_nn_batch_size) {
+        ubatch[u] = nb;
+        c4o_write_planes(&upos[u], planes + (size_t)84 * nb);
+        nb++;
+      } else {
+        ubatch[u] = -1;
+      }
+    }
+    st.nn_calls++;
+    st.nn_positions += (uint64_t)nb;
+    if (eval(eval_ctx, best_model, nb, planes, lp, qp, qn) != 0) { rc = C4O_ERR_DEGENERATE_POLICY; break; }
+    /* answered games go to the workers in one batch, the others stay pending (self_play.rs:225-236) */
+    uint64_t n_jobs = 0, w = 0;
+    for (uint64_t k = 0; k < n_pend; k++) {
+      uint64_t gi = pend[k];
+      int b = ubatch[game_uid[gi]];
+      if (b < 0) { pend[w++] = gi; continue; }
+      c4o_job* j = &out_jobs[n_jobs++];
+      j->game = gi;
+      memcpy(j->lp, lp + 7 * b, sizeof j->lp);
+      j->qp = qp[b]; j->qn = qn[b];
+    }
+    n_pend = w;
+    async_push_jobs(&a, out_jobs, n_jobs);
+  }
+  if (rc == C4O_OK && a.error) rc = a.error;
+  if (rc != C4O_OK || a.n_remaining > 0) {
+    /* error path: release the workers still waiting for jobs */
+    c4o_job pill;
+    memset(&pill, 0, sizeof pill);
+    pill.game = UINT64_MAX;
+    for (int w = 0; w < started; w++) async_push_jobs(&a, &pill, 1);
+  }
+  for (int w = 0; w < started; w++) pthread_join(th[w], NULL);
+
+  uint64_t off = 0;
+  for (uint64_t i = 0; i < n_games; i++) {
+    out_offsets[i] = off;
+    if (rc == C4O_OK && a.n_out[i] > 0) {
+      memcpy(out_samples + off, a.tmp_samples + 43 * i, sizeof(c4o_sample) * (size_t)a.n_out[i]);
+      off += (uint64_t)a.n_out[i];
+    }
+    c4o_counters c;
+    c4o_game_counters(a.games[i], &c);
+    st.tree.sims += c.sims; st.tree.sims_terminal_root += c.sims_terminal_root;
+    st.tree.select_levels += c.select_levels; st.tree.select_levels_discarded += c.select_levels_discarded;
+    st.tree.backup_nodes += c.backup_nodes;
+    st.tree.expansions += c.expansions; st.tree.nodes_created += c.nodes_created; st.tree.moves += c.moves;
+    c4o_game_free(a.games[i]);
+  }
+  out_offsets[n_games] = off;
+  st.n_samples = off;
+  if (stats) *stats = st;
+  free(th); free(pend); free(tab); free(game_uid); free(umodel); free(upos); free(ubatch);
+  free(planes); free(lp); free(qp); free(qn); free(out_jobs);
+  free(a.nn_items); free(a.jobs); free(a.games); free(a.n_out); free(a.tmp_samples);
+  pthread_mutex_destroy(&a.mu); pthread_cond_destroy(&a.cv);
+  pthread_mutex_destroy(&a.jmu); pthread_cond_destroy(&a.jcv);
   return rc;
 }

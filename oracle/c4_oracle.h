@@ -13,12 +13,16 @@
  *     each one by file:line).
  *   - libm expf/logf (what Rust f32::exp / f32::ln call): pinned by exhaustive sweep
  *     against the host glibc 2.35 libm (c4o_sweep_expf / c4o_sweep_logf).
- *   - move sampling RNG (rand 0.10.1 StdRng + WeightedIndex, chacha20 0.10.1): the
- *     crates' source is not in /root/reference and no reference test pins a sampled
- *     move => "PARITY UNPINNED" at this one boundary.  ChaCha block function is
- *     pinned by RFC 7539 / eSTREAM vectors and StdRng = ChaCha12 word order by the
- *     rand crate's own test_stdrng_construction vector; the PCG32 seed expansion
- *     and the float sampling are restated from the crates' documented algorithm.
+ *   - move sampling RNG (rand 0.10.1 StdRng + WeightedIndex, chacha20 0.10.1, rand_core
+ *     0.10.1): the crates' source is not in /root/reference and no reference test pins a
+ *     sampled move, so every stage is pinned by a vector the crates publish in their own
+ *     unit tests (tests/test_oracle_libm_rng.py): ChaCha block (RFC 7539 / eSTREAM),
+ *     StdRng = ChaCha12 word order (rand `test_stdrng_construction`), the PCG32 seed
+ *     expansion (rand_core `test_seed_from_u64` value-breakage constant), and
+ *     UniformFloat + cumulative weights + partition_point (rand WeightedIndex
+ *     `value_stability`, f32 weights under the crate's Pcg32 test generator).  Those
+ *     vectors are quoted from rand 0.8/0.9 and rand_core 0.6/0.9; a value-breaking change
+ *     in 0.10.1 cannot be excluded without its source (residual risk, stated in DESIGN.md).
  */
 #ifndef C4_ORACLE_H
 #define C4_ORACLE_H
@@ -165,6 +169,15 @@ int c4o_self_play(const c4o_game_metadata* reqs, uint64_t n_games, int max_nn_ba
                   uint64_t n_mcts_iterations, float c_exploration, float c_ply_penalty,
                   c4o_eval_fn eval, void* eval_ctx, int n_threads,
                   c4o_sample* out_samples, uint64_t* out_offsets, c4o_selfplay_stats* stats);
+
+/* The same job in the REFERENCE'S THREAD TOPOLOGY (self_play.rs:60-106): the calling thread is the
+ * NN thread (NNThread::loop_until_close, :196-237), n_threads - 1 worker threads are the MctsThreads
+ * (:268-323), games travel over two queues, network evaluation and tree work overlap.  Same samples
+ * as c4o_self_play; this is what bench.py's cpu_baseline leg times. */
+int c4o_self_play_async(const c4o_game_metadata* reqs, uint64_t n_games, int max_nn_batch_size,
+                        uint64_t n_mcts_iterations, float c_exploration, float c_ply_penalty,
+                        c4o_eval_fn eval, void* eval_ctx, int n_threads,
+                        c4o_sample* out_samples, uint64_t* out_offsets, c4o_selfplay_stats* stats);
 
 /* built-in evaluators usable as c4o_eval_fn (ctx ignored) */
 int c4o_eval_uniform(void* ctx, uint64_t model_id, int n, const float* planes,

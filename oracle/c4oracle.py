@@ -23,15 +23,26 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_DIR, "libc4oracle.so")
 
 
+def _source_hash() -> str:
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("c4_oracle.c", "c4_oracle.h", "Makefile"):
+        with open(os.path.join(_DIR, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:32]
+
+
 def build(force: bool = False) -> str:
-    """Compile the oracle with gcc (a second or two).  Returns the library path."""
-    src = os.path.join(_DIR, "c4_oracle.c")
-    hdr = os.path.join(_DIR, "c4_oracle.h")
-    stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr)
-    )
-    if force or stale:
+    """Compile the oracle with gcc (a second or two).  Returns the library path.  Stale = the hash of
+    the sources (kept beside the library) differs: mtimes mean nothing after a snapshot copy."""
+    stamp = _LIB_PATH + ".srchash"
+    want = _source_hash()
+    have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(_LIB_PATH) else None
+    if force or have != want:
         subprocess.run(["make", "-C", _DIR, "-B", "libc4oracle.so"], check=True, capture_output=True)
+        with open(stamp, "w") as f:
+            f.write(want)
     return _LIB_PATH
 
 
@@ -124,6 +135,8 @@ def lib() -> C.CDLL:
         "c4o_game_step": (C.c_int, [C.c_void_p, f32p, C.c_float, C.c_float, C.c_uint64, C.c_float, C.c_float]),
         "c4o_self_play": (C.c_int, [P(GameMetadataC), C.c_uint64, C.c_int, C.c_uint64, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_int, P(CSample), P(C.c_uint64), P(SelfPlayStats)]),
+        "c4o_self_play_async": (C.c_int, [P(GameMetadataC), C.c_uint64, C.c_int, C.c_uint64, C.c_float, C.c_float,
+                                          C.c_void_p, C.c_void_p, C.c_int, P(CSample), P(C.c_uint64), P(SelfPlayStats)]),
         "c4o_hash_eval_pos": (None, [C.c_uint64, C.c_uint64, f32p, f32p, f32p]),
     }
     for name, (res, args) in sig.items():
@@ -361,13 +374,17 @@ NpEval = Callable[[int, np.ndarray], Tuple[np.ndarray, np.ndarray, np.ndarray]]
 
 def self_play(reqs: Sequence[Tuple[int, int, int]], max_nn_batch_size: int, n_mcts_iterations: int,
               c_exploration: float, c_ply_penalty: float, evaluator="uniform", n_threads: int = 1,
-              dirichlet: Tuple[float, float] = (0.0, 0.0)):
+              dirichlet: Tuple[float, float] = (0.0, 0.0), topology: str = "lockstep"):
     """Oracle restatement of self_play.rs:39-129.
 
     `evaluator`: "uniform" | "zeros" | "hash" (built-in C evaluators) or a Python callable
     with the reference callback signature cb(model_id, float32[B,2,6,7]) ->
     (float32[B,7], float32[B], float32[B]) (pybridge.rs:170-198).
     Returns (dict game_id -> [SampleRec], stats dict).  Result order is per reqs order.
+
+    topology="async" runs the reference's thread topology (c4o_self_play_async): this thread is the
+    NN thread, n_threads - 1 worker threads run the MCTS jobs, evaluation and tree work overlap.
+    Same samples either way.
     """
     L = lib()
     n = len(reqs)
@@ -401,8 +418,11 @@ def self_play(reqs: Sequence[Tuple[int, int, int]], max_nn_batch_size: int, n_mc
         keep = EVAL_FN(_cb)
         fn = C.cast(keep, C.c_void_p)
     L.c4o_self_play_set_dirichlet(float(dirichlet[0]), float(dirichlet[1]))  # extension; (0, 0) = off
-    rc = L.c4o_self_play(arr, n, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty,
-                         fn, None, n_threads, out, offs, C.byref(stats))
+    if topology not in ("lockstep", "async"):
+        raise ValueError("topology must be 'lockstep' or 'async'")
+    entry = L.c4o_self_play_async if topology == "async" else L.c4o_self_play
+    rc = entry(arr, n, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty,
+               fn, None, n_threads, out, offs, C.byref(stats))
     L.c4o_self_play_set_dirichlet(0.0, 0.0)
     if keep is not None and err:
         raise err[0]

@@ -1,0 +1,43 @@
+"""Child process of tests/test_gpu_sharded.py: one rank of play_games_sharded on the (shared) GPU.
+
+    python tests/_sharded_worker.py RANK WORLD PORT OUT_DIR N_GAMES N_ITER MODE
+
+Started as a fresh process (nothing here runs before the interpreter starts: no GPU state is
+inherited), backend gloo: the records are staged through the host, everything else is the product
+path (real sessions, device packing, both collectives, the merge)."""
+import os
+import pickle
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, out_dir, n_games, n_iter, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = port
+    import torch
+    import torch.distributed as dist
+
+    from c4a0_amd import GameMetadata
+    from c4a0_amd.distributed import play_games_sharded
+    from tests.helpers import GraphSafeHashEval, hash_eval_torch
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    reqs = [GameMetadata(1000 + 7 * i, 0, 0) for i in range(n_games)]
+    stats = {}
+    if mode == "graph2":     # HIP-graph replay, two concurrent sessions per rank
+        res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, evaluator=GraphSafeHashEval(), device="cuda:0",
+                                 resident_games=16, concurrent_sessions=2, stats=stats)
+    else:                    # eager single session per rank, slots refilled from the rank's queue
+        res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, evaluator=hash_eval_torch, device="cuda:0",
+                                 resident_games=8, stats=stats)
+    with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
+        pickle.dump({"cbor": res.to_cbor(), "allgather": stats["sample_allgather"], "games_done": stats.get("games_done")}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,22 @@ def hash_eval_torch(planes):
     return logits, torch.stack([qp, qn], dim=1)
 
 
+class GraphSafeHashEval:
+    """hash_eval_torch as a graph-safe device evaluator (pure device work written into the caller's
+    tensors): lets the parity tests drive the HIP-graph / concurrent-session paths of play_games with
+    an evaluator whose answers are exact integers of the position (independent of batch shape)."""
+    graph_safe = True
+    dtype = None
+
+    def __call__(self, planes, out_logprobs=None, out_q=None):
+        lp, q = hash_eval_torch(planes)
+        if out_logprobs is None:
+            return lp, q
+        out_logprobs.copy_(lp)
+        out_q.copy_(q)
+        return out_logprobs, out_q
+
+
 def uniform_eval_torch(planes):
     """self_play.rs:391-403 UniformEvalPos on device."""
     import torch

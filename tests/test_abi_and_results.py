@@ -128,6 +128,16 @@ def test_pickle_add_unique_split():
         pgr.score_policies("a", "b", "c")
 
 
+def test_split_train_test_rounds_half_away_from_zero():
+    """pybridge.rs:114: `(len as f32 * train_frac).round()` -- Rust's f32::round rounds halves away
+    from zero (5 games at 0.5 -> 3 training games), numpy's round would give 2."""
+    from c4a0_amd import GameMetadata, GameResult, PlayGamesResult, Sample
+    mk = lambda i: GameResult(GameMetadata(i, 0, 0), [Sample(1 << i, 0, [1 / 7] * 7, 0.0, 0.0)])
+    for n, frac, want in [(5, 0.5, 3), (3, 0.5, 2), (7, 0.5, 4), (4, 0.5, 2), (10, 0.25, 3), (10, 0.24, 2), (1, 0.5, 1)]:
+        tr, te = PlayGamesResult([mk(i) for i in range(n)]).split_train_test(frac, 7)
+        assert (len(tr), len(te)) == (want, n - want), (n, frac)
+
+
 def test_results_from_records_roundtrip():
     from c4a0_amd import GameMetadata
     from c4a0_amd.results import results_from_records

@@ -45,27 +45,25 @@ def _worker(rank, world, port, n_games, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from c4a0_amd.distributed import all_gather_records, merge_rank_records, shard_indices
+    from c4a0_amd.distributed import gather_shards, merge_shards, shard_indices
+    from c4a0_amd.session import SAMPLE_DTYPE
 
     ids = np.arange(100, 100 + n_games)
     mine = ids[shard_indices(n_games, rank, world)]
     recs, counts = _records_for(mine.tolist())
     local = torch.from_numpy(recs.view(np.uint8).reshape(-1, 64).copy())
-    gathered = all_gather_records(local)
-    cnt_t = torch.zeros(n_games, dtype=torch.int64)  # counts travel the same way (padded to the largest shard)
-    cnt_t[: counts.size] = torch.from_numpy(counts.astype(np.int64))
-    all_counts = [torch.zeros_like(cnt_t) for _ in range(world)]
-    dist.all_gather(all_counts, cnt_t)
-    from c4a0_amd.session import SAMPLE_DTYPE
-    per_rank = [g.numpy().reshape(-1).view(SAMPLE_DTYPE) for g in gathered]
-    merged, mcounts = merge_rank_records(per_rank, n_games, world, [c.numpy().astype(np.uint32) for c in all_counts])
+    per_rank, per_counts = gather_shards(local, counts, n_games)          # the two collectives of the product path
+    merged_t, mcounts = merge_shards(per_rank, per_counts, n_games)      # torch form (what play_games_sharded runs)
+    merged = merged_t.numpy().reshape(-1).view(SAMPLE_DTYPE)
+    merged_np, mcounts_np = merge_shards([p.numpy().reshape(-1).view(SAMPLE_DTYPE) for p in per_rank], per_counts, n_games)
+    assert merged_np.tobytes() == merged.tobytes() and np.array_equal(mcounts, mcounts_np)   # numpy form agrees
     np.save(os.path.join(out_dir, f"merged_{rank}.npy"), merged)
     np.save(os.path.join(out_dir, f"counts_{rank}.npy"), mcounts)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_games", [7, 10])
+@pytest.mark.parametrize("n_games", [1, 7, 10])
 def test_two_rank_shard_and_allgather(tmp_path, n_games):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, n_games, str(tmp_path)), nprocs=world, join=True)

@@ -1,0 +1,195 @@
+"""Every BASELINE.json configuration (and bench.py's own configuration) through the HIP path against
+the oracle, at full size.
+
+The oracle cannot replay 4 096 games x 10 000 simulations inside the suite's budget, so each test
+checks EVERY game structurally (size-independent properties of the domain, tests/test_gpu_full_size.py)
+and replays a subset of the games in the oracle, bit for bit:
+  * hash evaluator (an exact integer function of the position): the oracle runs the same games;
+  * bf16 network: T3 replay -- the run logs every (leaf -> evaluator output) pair the
+    subset's slots consumed, the oracle replays those games with a lookup evaluator.
+Reference: rust/src/self_play.rs:268-323, mcts.rs:83-108."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+# ---------------------------------------------------------------------------------------------
+def _net(blocks, channels, seed=1337):
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    torch.manual_seed(seed)
+    return InferenceNet(ConnectFourNet(ModelConfig(blocks, channels, 4, 2)), torch.device("cuda:0"), dtype=torch.bfloat16)
+
+
+def _run_logged(net, ids, n_slots, n_iter, log_slots, dirichlet=None):
+    """One eager session; every step, the evaluator rows of `log_slots` (input planes, outputs) are
+    appended to a device-side log.  Returns (records, counts, counters, table position -> outputs)."""
+    from c4a0_amd.session import DeviceSession
+    from tests.helpers import planes_to_pos_np
+
+    dev = torch.device("cuda:0")
+    s = DeviceSession(n_slots, n_iter, 6.6, 0.01, device=dev, planes_dtype=torch.bfloat16)
+    s.set_games([(g, 0, 0) for g in ids])
+    if dirichlet is not None:
+        s.set_dirichlet(*dirichlet)
+    idx = torch.as_tensor(np.asarray(log_slots, dtype=np.int64), device=dev)
+    log_p, log_lp, log_q = [], [], []
+
+    def log(_step):   # planes hold the leaves, logprobs/q the evaluator's answers for them
+        log_p.append(s.planes.index_select(0, idx))
+        log_lp.append(s.logprobs.index_select(0, idx))
+        log_q.append(s.q.index_select(0, idx))
+
+    s.run(net, on_step=log, poll_every=64)
+    recs, counts, ctr = s.drain_samples(), s.sample_counts(), s.counters()
+    s.close()
+    planes = torch.cat(log_p).float().cpu().numpy()
+    lp, q = torch.cat(log_lp).cpu().numpy(), torch.cat(log_q).cpu().numpy()
+    mask, value = planes_to_pos_np(planes)
+    table = {}
+    for m, v, a, b in zip(mask.tolist(), value.tolist(), lp, q):
+        val = (a.tobytes(), b.tobytes())
+        assert table.setdefault((m, v), val) == val, "the evaluator must be a function of the position"
+    return recs, counts, ctr, table
+
+
+def _oracle_replay(table, ids, n_iter, dirichlet=(0.0, 0.0)):
+    from oracle import c4oracle as O
+    from tests.helpers import oracle_samples_by_game, planes_to_pos_np
+
+    zeros = (np.zeros(7, np.float32).tobytes(), np.zeros(2, np.float32).tobytes())
+
+    def answer(m, v):
+        # the device never shows a terminal leaf to the evaluator; the reference asks and ignores
+        # the answer (mcts.rs:92-98)
+        if (m, v) not in table:
+            assert O.terminal_state(O.Pos(m, v)) != 0, "a non-terminal leaf the device never evaluated"
+            return zeros
+        return table[(m, v)]
+
+    def lookup(_model_id, x):
+        mask, value = planes_to_pos_np(x)
+        ans = [answer(int(m), int(v)) for m, v in zip(mask, value)]
+        lp = np.stack([np.frombuffer(a[0], dtype=np.float32) for a in ans])
+        q = np.stack([np.frombuffer(a[1], dtype=np.float32) for a in ans])
+        return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
+
+    want, _ = O.self_play([(g, 0, 0) for g in ids], 64, n_iter, 6.6, 0.01, lookup, dirichlet=dirichlet)
+    return oracle_samples_by_game(want)
+
+
+def _subset(recs, sub):
+    from tests.helpers import samples_by_game
+
+    return samples_by_game(recs[np.isin(recs["game_id"], np.array(sub, dtype=np.uint64))])
+
+
+def _hash_run(ids, n_slots, n_iter):
+    from c4a0_amd.session import DeviceSession
+    from tests.helpers import GraphSafeHashEval
+
+    s = DeviceSession(n_slots, n_iter, 6.6, 0.01, planes_dtype=torch.bfloat16)
+    s.set_games([(g, 0, 0) for g in ids])
+    s.run(GraphSafeHashEval(), steps_per_graph=16)
+    recs, counts, ctr = s.drain_samples(), s.sample_counts(), s.counters()
+    s.close()
+    return recs, counts, ctr
+
+
+# ---------------------------------------------------------------------------------------------
+def test_config4_4096_games_n800_hash_evaluator_structure_and_oracle_subset():
+    """BASELINE config 4's tree shape: 4 096 concurrent games, n_mcts_iterations = 800 (deep trees,
+    the largest arenas, paths beyond 16 levels)."""
+    from oracle import c4oracle as O
+    from tests.helpers import oracle_samples_by_game
+    from tests.test_gpu_full_size import _check_structure
+
+    n, n_iter = 4096, 800
+    ids = list(range(70000, 70000 + n))
+    recs, counts, ctr = _hash_run(ids, n, n_iter)
+    assert ctr["games_done"] == n and ctr["error"] == 0 and ctr["samples"] == len(recs) == counts.sum()
+    _check_structure(recs, counts, ids)
+    assert ctr["sims"] / n > 7 * 300
+    sub = sorted(np.random.default_rng(4).choice(ids, 16, replace=False).tolist())
+    want, _ = O.self_play([(g, 0, 0) for g in sub], 64, n_iter, 6.6, 0.01, "hash", n_threads=8)
+    assert _subset(recs, sub) == oracle_samples_by_game(want)
+
+
+def test_config4_4096_games_n800_8x64_network_t3_replay():
+    """BASELINE config 4 itself: 4 096 games, n = 800, 8-block / 64-channel bf16 ResNet (4 policy and
+    2 value layers), T3 replay of a subset by the oracle."""
+    from tests.test_gpu_full_size import _check_structure
+
+    n, n_iter = 4096, 800
+    ids = list(range(n))
+    log_slots = sorted(np.random.default_rng(44).choice(n, 12, replace=False).tolist())   # no refill: slot g plays game g
+    recs, counts, ctr, table = _run_logged(_net(8, 64), ids, n, n_iter, log_slots)
+    assert ctr["games_done"] == n and ctr["error"] == 0
+    _check_structure(recs, counts, ids)
+    assert _subset(recs, log_slots) == _oracle_replay(table, log_slots, n_iter)
+
+
+@pytest.mark.parametrize("dirichlet", [None, (0.3, 0.25)])
+def test_config5_per_rank_8192_games_n200_8x64_network_plain_and_dirichlet(dirichlet):
+    """BASELINE config 5, one rank's share: 8 192 games, n = 200, 8 x 64 network, temperature schedule
+    (always on: self_play.rs:294-299), without and with Dirichlet root noise (extension; the oracle's
+    c4o_dirichlet is its specification).  Game ids follow the rank-3-of-8 shard pattern."""
+    from tests.test_gpu_full_size import _check_structure
+
+    n, n_iter = 8192, 200
+    ids = [3 + 8 * i for i in range(n)]
+    log_slots = sorted(np.random.default_rng(5).choice(n, 16, replace=False).tolist())
+    recs, counts, ctr, table = _run_logged(_net(8, 64), ids, n, n_iter, log_slots, dirichlet=dirichlet)
+    assert ctr["games_done"] == n and ctr["error"] == 0
+    _check_structure(recs, counts, ids)
+    sub = [ids[g] for g in log_slots]
+    assert _subset(recs, sub) == _oracle_replay(table, sub, n_iter, dirichlet or (0.0, 0.0))
+
+
+def test_config3_shard_pattern_equals_the_single_rank_run():
+    """BASELINE config 3: 32 768 games sharded over 8 ranks, id = r + 8 i, 4 096 resident per rank.
+    Ranks 0 and 5 of that pattern, each played alone, give exactly the records those games get when
+    ONE session plays all 32 768 (which slot, session or rank plays a game changes nothing)."""
+    from oracle import c4oracle as O
+    from tests.helpers import oracle_samples_by_game
+
+    n_all, world, n_iter = 32768, 8, 100
+    all_ids = list(range(n_all))
+    full, full_counts, ctr = _hash_run(all_ids, 4096, n_iter)
+    assert ctr["games_done"] == n_all and ctr["error"] == 0
+    offs = np.concatenate([[0], np.cumsum(full_counts.astype(np.int64))])
+    for r in (0, 5):
+        ids = all_ids[r::world]
+        recs, counts, c = _hash_run(ids, 4096, n_iter)
+        assert c["games_done"] == len(ids)
+        assert np.array_equal(counts, full_counts[r::world])
+        want = np.concatenate([full[offs[g]:offs[g + 1]] for g in ids])
+        assert recs.tobytes() == want.tobytes()
+    sub = [5 + 8 * i for i in (0, 17, 900, 4095)]
+    ora, _ = O.self_play([(g, 0, 0) for g in sub], 64, n_iter, 6.6, 0.01, "hash")
+    assert _subset(full, sub) == oracle_samples_by_game(ora)
+
+
+def test_bench_configuration_graph_two_sessions_equals_eager_and_oracle():
+    """bench.py's configuration: BASELINE config 2's network (4 blocks x 32 channels, 4 policy / 2
+    value layers, bf16), n = 100, 4 096 resident games as TWO concurrent sessions of 2 048 replaying
+    HIP graphs, slots refilled from the queue (8 192 games).  Its samples must equal, byte for byte,
+    the eager one-session run's, and that run is replayed by the oracle (T3) on a subset."""
+    import c4a0_amd
+
+    n, n_iter = 8192, 100
+    net = _net(4, 32)
+    ids = list(range(n))
+    log_slots = sorted(np.random.default_rng(2).choice(4096, 24, replace=False).tolist())   # first generation: slot g plays game g
+    recs, counts, ctr, table = _run_logged(net, ids, 4096, n_iter, log_slots)
+    assert ctr["games_done"] == n and ctr["error"] == 0
+    assert _subset(recs, log_slots) == _oracle_replay(table, log_slots, n_iter)
+    st = {}
+    res = c4a0_amd.play_games([c4a0_amd.GameMetadata(g, 0, 0) for g in ids], 4096, n_iter, 6.6, 0.01, evaluator=net,
+                              resident_games=4096, concurrent_sessions=2, stats=st)
+    assert st["concurrent_sessions"] == 2 and st["n_slots"] == 4096 and st["games_done"] == n
+    got, got_counts = res.to_records()
+    assert np.array_equal(got_counts, counts)
+    assert got.tobytes() == recs.tobytes()

@@ -4,8 +4,15 @@
   restatement is swept against the HOST libm.  The default run strides the sweep; `-m slow`
   runs every bit pattern.
 * rand 0.10.1 / chacha20 0.10.1 / rand_core 0.10.1 (Cargo.lock:1585-1593,269-277,1621-1622;
-  call site mcts.rs:214-222): ChaCha block pinned by published vectors; the rest restated
-  from the crates' documented algorithm -- PARITY UNPINNED against the real crates.
+  call site mcts.rs:214-222).  The crates' source is not in /root/reference; every stage of
+  `StdRng::seed_from_u64(s)` -> `WeightedIndex<f32>::sample` is pinned by a vector the crates
+  publish in their own unit tests (value-stability tests: they exist so that these values do
+  not change between releases): the ChaCha block (RFC 7539, eSTREAM), StdRng = ChaCha12 word
+  order (`test_stdrng_construction`), the PCG32 seed expansion (`rand_core`'s
+  `test_seed_from_u64` value-breakage constant) and UniformFloat / cumulative weights /
+  partition_point (`WeightedIndex`'s `value_stability` under the crate's Pcg32 test
+  generator).  The vectors are those of rand 0.8/0.9 and rand_core 0.6/0.9; a silent
+  value-breaking change in 0.10.1 cannot be excluded without its source.
 """
 import ctypes as C
 import struct
@@ -127,6 +134,64 @@ def test_seed_expansion_and_first_word_regression():
         assert L.c4o_rng_first_u32(seed) == first
         got = np.frombuffer(struct.pack("<I", 0x3F800000 | (first >> 9)), dtype=np.float32)[0] - np.float32(1.0)
         assert float(got) == u01
+
+
+def test_seed_from_u64_value_breakage_constant_of_rand_core():
+    """rand_core's own unit test `test_seed_from_u64` (rand_core 0.5-0.9 src/lib.rs) ends with a
+    "value-breakage test": a SeedableRng with an 8-byte seed, read little-endian, gives
+    seed_from_u64(0) == 5029875928683246316.  It pins the expansion the oracle (and the device)
+    use: PCG32 with MUL 6364136223846793005 / INC 11634580027462260723, the state advanced BEFORE
+    each output, XSH-RR output, words copied little-endian in order."""
+    key = O.seed_key(0)
+    assert int.from_bytes(key[:8], "little") == 5029875928683246316
+
+
+class _Pcg32:
+    """rand_pcg::Pcg32 = Lcg64Xsh32 (the generator behind rand's `crate::test::rng(seed)`,
+    `Pcg32::new(seed, 11634580027462260723)`): needed only to replay the crate's vectors."""
+    MUL, M64 = 6364136223846793005, (1 << 64) - 1
+
+    def __init__(self, state, stream):
+        self.inc = ((stream << 1) | 1) & self.M64
+        self.state = (state + self.inc) & self.M64
+        self._step()
+
+    def _step(self):
+        self.state = (self.state * self.MUL + self.inc) & self.M64
+
+    def next_u32(self):
+        st = self.state
+        self._step()
+        xs = (((st >> 18) ^ st) >> 27) & 0xFFFFFFFF
+        rot = st >> 59
+        return ((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF
+
+
+def test_weighted_index_value_stability_vector_of_the_rand_crate():
+    """rand's own `value_stability` test of WeightedIndex (rand 0.8/0.9
+    src/distributions/weighted_index.rs): with `crate::test::rng(701)`, ten samples of
+    WeightedIndex::new([0.7f32, 0.1, 0.1, 0.1]) are [0, 0, 0, 1, 0, 0, 2, 3, 0, 0].  The oracle's
+    c4o_weighted_index consumes one next_u32 per sample, so this pins UniformFloat<f32>::new (the
+    scale loop), ::sample ((u >> 9 | exponent 0) - 1.0) * scale + low, the left-to-right f32
+    cumulative sums and partition_point(w <= x).  Trailing zero weights change neither the total
+    nor the chosen index."""
+    rng = _Pcg32(701, 11634580027462260723)
+    w = [0.7, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0]
+    got = [O.weighted_index(w, rng.next_u32()) for _ in range(10)]
+    assert got == [0, 0, 0, 1, 0, 0, 2, 3, 0, 0]
+    # the same generator replays the crate's f64 vector through a plain-Python restatement of the
+    # same algorithm (next_u64 = low word first): a check of _Pcg32 itself
+    rng = _Pcg32(701, 11634580027462260723)
+    cum, total, out = [1.0, 1.0 + 0.999, 1.0 + 0.999 + 0.998], 1.0 + 0.999 + 0.998 + 0.997, []
+    scale = total
+    while scale * (1.0 - 2.0 ** -52) + 0.0 >= total:
+        scale = struct.unpack("<d", struct.pack("<Q", struct.unpack("<Q", struct.pack("<d", scale))[0] - 1))[0]
+    for _ in range(10):
+        lo = rng.next_u32()
+        u = (rng.next_u32() << 32) | lo
+        x = (struct.unpack("<d", struct.pack("<Q", 0x3FF0000000000000 | (u >> 12)))[0] - 1.0) * scale + 0.0
+        out.append(sum(1 for c in cum if c <= x))
+    assert out == [2, 2, 1, 3, 2, 1, 3, 3, 2, 1]
 
 
 def test_weighted_index_semantics():

@@ -247,3 +247,34 @@ def test_dirichlet_off_by_default_and_changes_games_when_on():
     assert a == b == d and a != c
     for s in c.values():   # noisy games are still well-formed
         assert O.terminal_state(O.Pos(s[-1].mask, s[-1].value)) != 0
+
+
+def test_async_topology_gives_the_samples_of_the_lockstep_restatement():
+    """c4o_self_play_async = the reference's thread topology (self_play.rs:60-106: one NN thread,
+    ncpu-1 MctsThreads, two queues).  Batching depends on thread timing, a game's samples do not
+    (each trajectory depends on the answers for its own leaves only): same samples and tree
+    counters as the lock-step restatement, for built-in and Python evaluators, several models,
+    batch caps smaller than the job, and more threads than games."""
+    from tests.helpers import hash_eval_np
+
+    def flat(res):
+        return {g: [(s.mask, s.value, tuple(s.policy), s.q_penalty, s.q_no_penalty) for s in ss] for g, ss in res.items()}
+
+    reqs = [(3 * i + 1, i % 3, (i + 1) % 3) for i in range(90)]
+    want, wst = O.self_play(reqs, 7, 15, 6.6, 0.01, "hash")
+    for threads in (2, 5):
+        got, gst = O.self_play(reqs, 7, 15, 6.6, 0.01, "hash", n_threads=threads, topology="async")
+        assert flat(got) == flat(want)
+        for k in ("sims", "backup_nodes", "expansions", "moves", "n_samples"):
+            assert gst[k] == wst[k], k
+    got, _ = O.self_play(reqs[:20], 64, 9, 6.6, 0.01, hash_eval_np, n_threads=3, topology="async")
+    want2, _ = O.self_play(reqs[:20], 64, 9, 6.6, 0.01, "hash")
+    assert flat(got) == flat(want2)
+    got, _ = O.self_play(reqs[:2], 64, 9, 6.6, 0.01, "hash", n_threads=8, topology="async")
+    assert flat(got) == {g: v for g, v in flat(want2).items() if g in (1, 4)}
+    assert O.self_play([], 64, 9, 6.6, 0.01, "hash", n_threads=4, topology="async")[0] == {}
+
+    def failing(_m, _x):
+        raise RuntimeError("evaluator failure")
+    with pytest.raises(RuntimeError):
+        O.self_play(reqs[:8], 64, 9, 6.6, 0.01, failing, n_threads=3, topology="async")
