@@ -1111,39 +1111,95 @@ int c4o_self_play(const c4o_game_metadata* reqs, uint64_t n_games, int max_nn_ba
  * alone.  Used by bench.py's cpu_baseline leg and checked against c4o_self_play in the tests.
  * ---------------------------------------------------------------------------------------- */
 #include <pthread.h>
+#include <sched.h>
+#include <time.h>
 
 typedef struct {
   uint64_t game;      /* index into games[]; UINT64_MAX = MctsJob::PoisonPill (self_play.rs:317-322) */
   float lp[7], qp, qn;
 } c4o_job;
 
+/* Bounded multi-producer multi-consumer queue (D. Vyukov's array queue: one sequence number per
+ * cell), standing in for crossbeam_channel::bounded (self_play.rs:51-53): lock-free, a blocked
+ * receiver spins briefly, then yields, then sleeps -- as crossbeam's Backoff/park does. */
+typedef struct { uint64_t seq; c4o_job job; } c4o_cell;
 typedef struct {
-  pthread_mutex_t mu;
-  pthread_cond_t cv;
-  /* nn_queue: games waiting for the network (self_play.rs:51) */
-  uint64_t* nn_items; uint64_t nn_head, nn_tail, nn_cap; int nn_closed;
-  /* mcts_queue: evaluated games waiting for a worker (self_play.rs:52) */
-  c4o_job* jobs; uint64_t job_head, job_tail, job_cap;
-  pthread_mutex_t jmu;
-  pthread_cond_t jcv;
-  /* shared state */
+  c4o_cell* cells; uint64_t mask;
+  uint64_t enq __attribute__((aligned(64)));
+  uint64_t deq __attribute__((aligned(64)));
+} c4o_queue;
+
+static void queue_init(c4o_queue* q, uint64_t min_cap) {
+  uint64_t cap = 2;
+  while (cap < min_cap) cap <<= 1;
+  q->cells = (c4o_cell*)malloc(sizeof(c4o_cell) * cap);
+  q->mask = cap - 1;
+  for (uint64_t i = 0; i < cap; i++) q->cells[i].seq = i;
+  q->enq = q->deq = 0;
+}
+
+static int queue_push(c4o_queue* q, const c4o_job* j) {
+  uint64_t pos = __atomic_load_n(&q->enq, __ATOMIC_RELAXED);
+  for (;;) {
+    c4o_cell* c = &q->cells[pos & q->mask];
+    const int64_t dif = (int64_t)(__atomic_load_n(&c->seq, __ATOMIC_ACQUIRE) - pos);
+    if (dif == 0) {
+      if (__atomic_compare_exchange_n(&q->enq, &pos, pos + 1, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+        c->job = *j;
+        __atomic_store_n(&c->seq, pos + 1, __ATOMIC_RELEASE);
+        return 1;
+      }
+    } else if (dif < 0) {
+      return 0; /* full: cannot happen, every game is in at most one queue and the rings hold them all */
+    } else {
+      pos = __atomic_load_n(&q->enq, __ATOMIC_RELAXED);
+    }
+  }
+}
+
+static int queue_try_pop(c4o_queue* q, c4o_job* out) {
+  uint64_t pos = __atomic_load_n(&q->deq, __ATOMIC_RELAXED);
+  for (;;) {
+    c4o_cell* c = &q->cells[pos & q->mask];
+    const int64_t dif = (int64_t)(__atomic_load_n(&c->seq, __ATOMIC_ACQUIRE) - (pos + 1));
+    if (dif == 0) {
+      if (__atomic_compare_exchange_n(&q->deq, &pos, pos + 1, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+        *out = c->job;
+        __atomic_store_n(&c->seq, pos + q->mask + 1, __ATOMIC_RELEASE);
+        return 1;
+      }
+    } else if (dif < 0) {
+      return 0; /* empty */
+    } else {
+      pos = __atomic_load_n(&q->deq, __ATOMIC_RELAXED);
+    }
+  }
+}
+
+static inline void backoff(unsigned* n) {
+  if (*n < 64) { __builtin_ia32_pause(); }
+  else if (*n < 256) { sched_yield(); }
+  else { struct timespec ts = {0, 20000}; nanosleep(&ts, NULL); }
+  (*n)++;
+}
+
+typedef struct {
+  c4o_queue nn_queue;   /* games waiting for the network (self_play.rs:51); only .game is used */
+  c4o_queue mcts_queue; /* evaluated games waiting for a worker (self_play.rs:52) */
+  int nn_closed;
   c4o_game** games; int* n_out; c4o_sample* tmp_samples;
   uint64_t n_remaining; int n_workers; int error;
   uint64_t n_iter; float c_exploration, c_ply_penalty;
 } c4o_async;
 
 static void async_push_nn(c4o_async* a, uint64_t gi) {
-  pthread_mutex_lock(&a->mu);
-  a->nn_items[a->nn_tail++ % a->nn_cap] = gi;
-  pthread_cond_signal(&a->cv);
-  pthread_mutex_unlock(&a->mu);
+  c4o_job j;
+  j.game = gi;
+  queue_push(&a->nn_queue, &j);
 }
 
 static void async_push_jobs(c4o_async* a, const c4o_job* j, uint64_t n) {
-  pthread_mutex_lock(&a->jmu);
-  for (uint64_t i = 0; i < n; i++) a->jobs[a->job_tail++ % a->job_cap] = j[i];
-  if (n == 1) pthread_cond_signal(&a->jcv); else pthread_cond_broadcast(&a->jcv);
-  pthread_mutex_unlock(&a->jmu);
+  for (uint64_t i = 0; i < n; i++) queue_push(&a->mcts_queue, &j[i]);
 }
 
 /* MctsThread::loop_until_close (self_play.rs:268-323) */
@@ -1151,10 +1207,8 @@ static void* async_worker(void* arg) {
   c4o_async* a = (c4o_async*)arg;
   for (;;) {
     c4o_job j;
-    pthread_mutex_lock(&a->jmu);
-    while (a->job_head == a->job_tail) pthread_cond_wait(&a->jcv, &a->jmu);
-    j = a->jobs[a->job_head++ % a->job_cap];
-    pthread_mutex_unlock(&a->jmu);
+    unsigned spins = 0;
+    while (!queue_try_pop(&a->mcts_queue, &j)) backoff(&spins);
     if (j.game == UINT64_MAX) break;
     c4o_game* g = a->games[j.game];
     int st = c4o_game_step(g, j.lp, j.qp, j.qn, a->n_iter, a->c_exploration, a->c_ply_penalty);
@@ -1177,10 +1231,7 @@ static void* async_worker(void* arg) {
       memset(&pill, 0, sizeof pill);
       pill.game = UINT64_MAX;
       for (int w = 0; w < a->n_workers - 1; w++) async_push_jobs(a, &pill, 1);
-      pthread_mutex_lock(&a->mu);
-      a->nn_closed = 1;
-      pthread_cond_signal(&a->cv);
-      pthread_mutex_unlock(&a->mu);
+      __atomic_store_n(&a->nn_closed, 1, __ATOMIC_RELEASE);
       break;
     }
   }
@@ -1199,11 +1250,9 @@ int c4o_self_play_async(const c4o_game_metadata* reqs, uint64_t n_games, int max
   const size_t ng = n_games ? n_games : 1;
   c4o_async a;
   memset(&a, 0, sizeof a);
-  pthread_mutex_init(&a.mu, NULL); pthread_cond_init(&a.cv, NULL);
-  pthread_mutex_init(&a.jmu, NULL); pthread_cond_init(&a.jcv, NULL);
   a.n_workers = n_threads - 1;
-  a.nn_cap = ng; a.nn_items = (uint64_t*)malloc(sizeof(uint64_t) * ng);
-  a.job_cap = ng + (size_t)n_threads; a.jobs = (c4o_job*)malloc(sizeof(c4o_job) * a.job_cap);
+  queue_init(&a.nn_queue, ng + 1);
+  queue_init(&a.mcts_queue, ng + (size_t)n_threads + 1);
   a.games = (c4o_game**)calloc(ng, sizeof(c4o_game*));
   a.n_out = (int*)calloc(ng, sizeof(int));
   a.tmp_samples = (c4o_sample*)malloc(sizeof(c4o_sample) * 43 * ng);
@@ -1213,7 +1262,7 @@ int c4o_self_play_async(const c4o_game_metadata* reqs, uint64_t n_games, int max
   for (uint64_t i = 0; i < n_games; i++) {
     a.games[i] = c4o_game_new(&start, reqs[i].game_id, reqs[i].player0_id, reqs[i].player1_id);
     c4o_game_set_dirichlet(a.games[i], g_sp_dir_alpha, g_sp_dir_eps);
-    a.nn_items[a.nn_tail++] = i; /* self_play.rs:55-58 */
+    async_push_nn(&a, i); /* self_play.rs:55-58 */
   }
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)a.n_workers);
   int started = 0;
@@ -1239,12 +1288,17 @@ int c4o_self_play_async(const c4o_game_metadata* reqs, uint64_t n_games, int max
   c4o_job* out_jobs = (c4o_job*)malloc(sizeof(c4o_job) * ng);
   int closed = 0;
   while (rc == C4O_OK && n_games > 0 && (!closed || n_pend > 0)) {
-    /* drain_queue: block while nothing is pending, then take everything that is there */
-    pthread_mutex_lock(&a.mu);
-    while (n_pend == 0 && a.nn_head == a.nn_tail && !a.nn_closed) pthread_cond_wait(&a.cv, &a.mu);
-    while (a.nn_head != a.nn_tail) pend[n_pend++] = a.nn_items[a.nn_head++ % a.nn_cap];
-    closed = a.nn_closed;
-    pthread_mutex_unlock(&a.mu);
+    /* drain_queue (self_play.rs:175-193): block while nothing is pending, then take everything that is there */
+    {
+      c4o_job j;
+      unsigned spins = 0;
+      for (;;) {
+        closed = __atomic_load_n(&a.nn_closed, __ATOMIC_ACQUIRE);
+        while (queue_try_pop(&a.nn_queue, &j)) pend[n_pend++] = j.game;
+        if (n_pend > 0 || closed || __atomic_load_n(&a.error, __ATOMIC_RELAXED)) break;
+        backoff(&spins);
+      }
+    }
     if (__atomic_load_n(&a.error, __ATOMIC_RELAXED)) break;
     if (n_pend == 0) continue;
     /* unique (model, leaf position) pairs of the pending games */
@@ -1345,8 +1399,6 @@ int c4o_self_play_async(const c4o_game_metadata* reqs, uint64_t n_games, int max
   if (stats) *stats = st;
   free(th); free(pend); free(tab); free(game_uid); free(umodel); free(upos); free(ubatch);
   free(planes); free(lp); free(qp); free(qn); free(out_jobs);
-  free(a.nn_items); free(a.jobs); free(a.games); free(a.n_out); free(a.tmp_samples);
-  pthread_mutex_destroy(&a.mu); pthread_cond_destroy(&a.cv);
-  pthread_mutex_destroy(&a.jmu); pthread_cond_destroy(&a.jcv);
+  free(a.nn_queue.cells); free(a.mcts_queue.cells); free(a.games); free(a.n_out); free(a.tmp_samples);
   return rc;
 }

@@ -25,7 +25,8 @@ def _net(blocks, channels, seed=1337):
 
 def _run_logged(net, ids, n_slots, n_iter, log_slots, dirichlet=None):
     """One eager session; every step, the evaluator rows of `log_slots` (input planes, outputs) are
-    appended to a device-side log.  Returns (records, counts, counters, table position -> outputs)."""
+    appended to a device-side log.  Returns (records, counts, counters, log) with log[slot] = the
+    sequence of (leaf position, outputs bytes) that slot's evaluator row went through, one per step."""
     from c4a0_amd.session import DeviceSession
     from tests.helpers import planes_to_pos_np
 
@@ -45,39 +46,48 @@ def _run_logged(net, ids, n_slots, n_iter, log_slots, dirichlet=None):
     s.run(net, on_step=log, poll_every=64)
     recs, counts, ctr = s.drain_samples(), s.sample_counts(), s.counters()
     s.close()
-    planes = torch.cat(log_p).float().cpu().numpy()
-    lp, q = torch.cat(log_lp).cpu().numpy(), torch.cat(log_q).cpu().numpy()
-    mask, value = planes_to_pos_np(planes)
-    table = {}
-    for m, v, a, b in zip(mask.tolist(), value.tolist(), lp, q):
-        val = (a.tobytes(), b.tobytes())
-        assert table.setdefault((m, v), val) == val, "the evaluator must be a function of the position"
-    return recs, counts, ctr, table
+    k = len(log_slots)
+    planes = torch.stack(log_p).float().cpu().numpy()                     # [steps, k, 2, 6, 7]
+    lp, q = torch.stack(log_lp).cpu().numpy(), torch.stack(log_q).cpu().numpy()
+    mask, value = planes_to_pos_np(planes.reshape(-1, 2, 6, 7))
+    mask, value = mask.reshape(-1, k), value.reshape(-1, k)
+    seq = {}
+    for j, slot in enumerate(log_slots):
+        seq[slot] = [((int(m), int(v)), a.tobytes(), b.tobytes()) for m, v, a, b in zip(mask[:, j], value[:, j], lp[:, j], q[:, j])]
+    return recs, counts, ctr, seq
 
 
-def _oracle_replay(table, ids, n_iter, dirichlet=(0.0, 0.0)):
+def _oracle_replay(seq_by_slot, slot_ids, n_iter, dirichlet=(0.0, 0.0)):
+    """T3: the oracle plays each logged game ALONE and is answered, leaf by leaf, with
+    what the device's evaluator said for that game's row at that step.  The k-th non-terminal leaf
+    the oracle asks about must BE the k-th leaf the device showed its evaluator (checked), so the
+    whole search sequence is compared, not only the samples.  Keyed by the game's own sequence and
+    not by position: a library GEMM's low bits may depend on the row a position sits in.
+    seq_by_slot[slot] as returned by _run_logged; slot_ids = [(slot, game id)]."""
     from oracle import c4oracle as O
     from tests.helpers import oracle_samples_by_game, planes_to_pos_np
 
-    zeros = (np.zeros(7, np.float32).tobytes(), np.zeros(2, np.float32).tobytes())
+    out = {}
+    for slot, gid in slot_ids:
+        seq, cursor = seq_by_slot[slot], [0]
 
-    def answer(m, v):
-        # the device never shows a terminal leaf to the evaluator; the reference asks and ignores
-        # the answer (mcts.rs:92-98)
-        if (m, v) not in table:
-            assert O.terminal_state(O.Pos(m, v)) != 0, "a non-terminal leaf the device never evaluated"
-            return zeros
-        return table[(m, v)]
+        def lookup(_model_id, x, seq=seq, cursor=cursor):
+            mask, value = planes_to_pos_np(x)
+            assert len(mask) == 1
+            pos = (int(mask[0]), int(value[0]))
+            if cursor[0] < len(seq) and seq[cursor[0]][0] == pos:
+                _p, a, b = seq[cursor[0]]
+                cursor[0] += 1
+                lp, q = np.frombuffer(a, dtype=np.float32), np.frombuffer(b, dtype=np.float32)
+                return lp.reshape(1, 7).copy(), q[:1].copy(), q[1:2].copy()
+            # the device never shows a terminal leaf to the evaluator when it can run that simulation in
+            # the launch that selected it; the reference asks and ignores the answer (mcts.rs:92-98)
+            assert O.terminal_state(O.Pos(*pos)) != 0, f"game {gid}: leaf {pos} is not the device's next leaf {seq[cursor[0]][0] if cursor[0] < len(seq) else None}"
+            return np.zeros((1, 7), np.float32), np.zeros(1, np.float32), np.zeros(1, np.float32)
 
-    def lookup(_model_id, x):
-        mask, value = planes_to_pos_np(x)
-        ans = [answer(int(m), int(v)) for m, v in zip(mask, value)]
-        lp = np.stack([np.frombuffer(a[0], dtype=np.float32) for a in ans])
-        q = np.stack([np.frombuffer(a[1], dtype=np.float32) for a in ans])
-        return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
-
-    want, _ = O.self_play([(g, 0, 0) for g in ids], 64, n_iter, 6.6, 0.01, lookup, dirichlet=dirichlet)
-    return oracle_samples_by_game(want)
+        want, _ = O.self_play([(gid, 0, 0)], 64, n_iter, 6.6, 0.01, lookup, dirichlet=dirichlet)
+        out.update(oracle_samples_by_game(want))
+    return out
 
 
 def _subset(recs, sub):
@@ -125,10 +135,10 @@ def test_config4_4096_games_n800_8x64_network_t3_replay():
     n, n_iter = 4096, 800
     ids = list(range(n))
     log_slots = sorted(np.random.default_rng(44).choice(n, 12, replace=False).tolist())   # no refill: slot g plays game g
-    recs, counts, ctr, table = _run_logged(_net(8, 64), ids, n, n_iter, log_slots)
+    recs, counts, ctr, seq = _run_logged(_net(8, 64), ids, n, n_iter, log_slots)
     assert ctr["games_done"] == n and ctr["error"] == 0
     _check_structure(recs, counts, ids)
-    assert _subset(recs, log_slots) == _oracle_replay(table, log_slots, n_iter)
+    assert _subset(recs, log_slots) == _oracle_replay(seq, [(g, ids[g]) for g in log_slots], n_iter)
 
 
 @pytest.mark.parametrize("dirichlet", [None, (0.3, 0.25)])
@@ -141,11 +151,11 @@ def test_config5_per_rank_8192_games_n200_8x64_network_plain_and_dirichlet(diric
     n, n_iter = 8192, 200
     ids = [3 + 8 * i for i in range(n)]
     log_slots = sorted(np.random.default_rng(5).choice(n, 16, replace=False).tolist())
-    recs, counts, ctr, table = _run_logged(_net(8, 64), ids, n, n_iter, log_slots, dirichlet=dirichlet)
+    recs, counts, ctr, seq = _run_logged(_net(8, 64), ids, n, n_iter, log_slots, dirichlet=dirichlet)
     assert ctr["games_done"] == n and ctr["error"] == 0
     _check_structure(recs, counts, ids)
     sub = [ids[g] for g in log_slots]
-    assert _subset(recs, sub) == _oracle_replay(table, sub, n_iter, dirichlet or (0.0, 0.0))
+    assert _subset(recs, sub) == _oracle_replay(seq, [(g, ids[g]) for g in log_slots], n_iter, dirichlet or (0.0, 0.0))
 
 
 def test_config3_shard_pattern_equals_the_single_rank_run():
@@ -175,21 +185,27 @@ def test_config3_shard_pattern_equals_the_single_rank_run():
 def test_bench_configuration_graph_two_sessions_equals_eager_and_oracle():
     """bench.py's configuration: BASELINE config 2's network (4 blocks x 32 channels, 4 policy / 2
     value layers, bf16), n = 100, 4 096 resident games as TWO concurrent sessions of 2 048 replaying
-    HIP graphs, slots refilled from the queue (8 192 games).  Its samples must equal, byte for byte,
-    the eager one-session run's, and that run is replayed by the oracle (T3) on a subset."""
+    HIP graphs, slots refilled from the queue (8 192 games).  Session p plays requests p, p + 2, ...;
+    each session's games are also played by an EAGER session of the same width (same evaluator batch
+    shape), one of them logged and replayed by the oracle (T3) on a subset; the graph-replayed
+    two-session job must return exactly the two eager runs' records, merged."""
     import c4a0_amd
+    from c4a0_amd.api import merge_parts
 
     n, n_iter = 8192, 100
     net = _net(4, 32)
     ids = list(range(n))
-    log_slots = sorted(np.random.default_rng(2).choice(4096, 24, replace=False).tolist())   # first generation: slot g plays game g
-    recs, counts, ctr, table = _run_logged(net, ids, 4096, n_iter, log_slots)
-    assert ctr["games_done"] == n and ctr["error"] == 0
-    assert _subset(recs, log_slots) == _oracle_replay(table, log_slots, n_iter)
+    log_slots = sorted(np.random.default_rng(2).choice(2048, 24, replace=False).tolist())   # first generation: slot g plays the session's game g
+    ids0, ids1 = ids[0::2], ids[1::2]
+    recs0, counts0, ctr0, seq = _run_logged(net, ids0, 2048, n_iter, log_slots)
+    assert ctr0["games_done"] == len(ids0) and ctr0["error"] == 0
+    assert _subset(recs0, [ids0[g] for g in log_slots]) == _oracle_replay(seq, [(g, ids0[g]) for g in log_slots], n_iter)
+    recs1, counts1, ctr1, _ = _run_logged(net, ids1, 2048, n_iter, [0])
+    want, want_counts = merge_parts(n, [(np.arange(0, n, 2), counts0, recs0), (np.arange(1, n, 2), counts1, recs1)])
     st = {}
     res = c4a0_amd.play_games([c4a0_amd.GameMetadata(g, 0, 0) for g in ids], 4096, n_iter, 6.6, 0.01, evaluator=net,
                               resident_games=4096, concurrent_sessions=2, stats=st)
     assert st["concurrent_sessions"] == 2 and st["n_slots"] == 4096 and st["games_done"] == n
     got, got_counts = res.to_records()
-    assert np.array_equal(got_counts, counts)
-    assert got.tobytes() == recs.tobytes()
+    assert np.array_equal(got_counts, want_counts)
+    assert got.tobytes() == want.tobytes()
