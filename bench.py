@@ -108,6 +108,46 @@ def cpu_baseline(net, device, n_iter: int, threads: int, budget_s: float = 20.0)
             "sims_per_s": st["sims"] / dt}
 
 
+def whole_job(args, device, real_stdout):
+    """`--whole-job`: the reference's OWN default self-play job (src/c4a0/main.py:40-51: 1 700 games,
+    n_mcts_iterations = 1 400, batch 2 000, 1-block / 32-channel network with 4 policy and 2 value
+    layers), played start to finish through `play_games` -- session set-up, HIP-graph capture, the
+    tail where finished slots idle, and the sample hand-over included -- in the three ways a caller
+    can use it: the unmodified numpy callback (training.py:179-189), the same call with a
+    `DeviceCallback` wrapper, and `evaluator=`.  Not the headline: one JSON line of its own."""
+    import c4a0_amd
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    torch.manual_seed(1337)
+    net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 4, 2)), device, dtype=torch.bfloat16)
+    n_games, n_iter = args.whole_job_games, args.whole_job_n_mcts
+    reqs = [c4a0_amd.GameMetadata(i, 0, 0) for i in range(n_games)]
+
+    def cb(_model_id, x):   # the shape of ConnectFourNet.forward_numpy (nn.py:119-130): H2D, forward, 3 x D2H
+        with torch.no_grad():
+            lp, q = net(torch.from_numpy(x).to(device))
+            lp, q = lp.float().cpu().numpy(), q.float().cpu().numpy()
+        return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
+
+    out, ref = {}, None
+    for name, kw in (("device_mode", dict(evaluator=net)), ("device_callback_wrapper", dict(py_eval_pos_cb=c4a0_amd.DeviceCallback(net, device))),
+                     ("numpy_callback", dict(py_eval_pos_cb=cb))):
+        st = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = c4a0_amd.play_games(reqs, 2000, n_iter, 6.6, 0.01, stats=st, **kw)
+        recs, _counts = res.to_records()
+        dt = time.perf_counter() - t0
+        ref = recs if ref is None else ref
+        out[name] = {"games_per_s": n_games / dt, "sims_per_s": st["sims"] / dt, "seconds": dt, "steps": st["steps"],
+                     "samples": int(len(recs)), "samples_identical_to_device_mode": bool(recs.tobytes() == ref.tobytes())}
+    line = {"metric": "whole-job self-play games/sec, the reference's default job", "value": out["device_mode"]["games_per_s"], "unit": "games/s",
+            "n_gpus": 1, "higher_is_better": True, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"src/c4a0/main.py:40-51 defaults: {n_games} games, n_mcts_iterations={n_iter}, max_nn_batch_size=2000, 1-block/32-ch ResNet (4 policy / 2 value layers) bf16"},
+            **out}
+    os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
+
 def main():
     # Only the JSON line may reach stdout: libraries (RCCL prints a version banner) write to the
     # process's fd 1 behind Python's back, so fd 1 is pointed at stderr for the whole run and the
@@ -142,6 +182,10 @@ def main():
     ap.add_argument("--sessions", type=int, default=2,
                     help="the resident games are split over this many sessions that replay their HIP graphs "
                          "concurrently on separate streams (1 = one session, one stream)")
+    ap.add_argument("--whole-job", action="store_true",
+                    help="instead of the steady-state bench: the reference's default self-play job, whole, in callback and device modes (own JSON line)")
+    ap.add_argument("--whole-job-games", type=int, default=1700)
+    ap.add_argument("--whole-job-n-mcts", type=int, default=1400)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,6 +199,8 @@ def main():
         sys.exit("bench.py needs a HIP device")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.whole_job:
+        return whole_job(args, device, real_stdout)
     from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig, flops_per_leaf
     from c4a0_amd.session import DeviceSession
 

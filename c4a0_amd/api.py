@@ -46,53 +46,83 @@ def _popcount64(x: np.ndarray) -> np.ndarray:
 class _CallbackEvaluator:
     """PyEvalPos (pybridge.rs:161-199) + the batching semantics of NNThread::loop_once
     (self_play.rs:196-237): per step, the unique (model, leaf position) pairs of all resident
-    games are evaluated in chunks of at most max_nn_batch_size, one model per call."""
+    games are evaluated in chunks of at most max_nn_batch_size, one model per call.
 
-    def __init__(self, session: DeviceSession, cb: Callable, max_nn_batch_size: int, slot_models):
+    The bookkeeping runs on the device: the session writes one int64 key per slot
+    (c4_session_leaf_keys), a device sort finds the unique positions and the slot -> unique-row map,
+    only the unique rows of the evaluator input travel to the host (pinned, one copy) and only the
+    unique answers travel back; the answers are fanned out to the slots by a device gather.  The
+    callback sees exactly what the reference's sees: float32 [B, 2, 6, 7], unique positions,
+    B <= max_nn_batch_size, one model per call."""
+
+    def __init__(self, session: DeviceSession, cb: Callable, max_nn_batch_size: int, p0: np.ndarray, p1: np.ndarray):
+        import ctypes as C
+
+        from ._lib import check
+        self._C, self._check = C, check
         self.s, self.cb, self.cap = session, cb, max(1, int(max_nn_batch_size))
-        self.slot_models = slot_models  # callable(ordinals) -> (player0_ids, player1_ids)
-        g = session.n_slots
-        self.lp = np.zeros((g, 7), dtype=np.float32)
-        self.q = np.zeros((g, 2), dtype=np.float32)
+        dev, g = session.device, session.n_slots
+        self.keys = torch.zeros(g, dtype=torch.int64, device=dev)
+        self.models_used = np.unique(np.concatenate([p0, p1]))
+        self.multi = self.models_used.size > 1
+        self.slot_models = session.bind_leaf_models() if self.multi else None   # the step kernel publishes mcts.rs:70-76 per slot
+        self.arange = torch.arange(g, dtype=torch.int64, device=dev)
+        # pinned staging: unique input rows out, unique answers back
+        self.h_planes = torch.empty((g, 2, 6, 7), dtype=torch.float32).pin_memory()
+        self.h_out = torch.empty((g, 9), dtype=torch.float32).pin_memory()
+        self.d_out = torch.empty((g, 9), dtype=torch.float32, device=dev)
         self.nn_positions = 0
+        if session.planes.dtype != torch.float32:
+            raise ValueError("the numpy callback takes float32 planes")
 
     def __call__(self, _planes: torch.Tensor):
-        mask, value, status, ordinal = self.s.leaves(with_ordinals=True)
-        act = np.nonzero(status == 1)[0]
-        if act.size:
-            p0, p1 = self.slot_models(ordinal[act])
-            am, av = mask[act], value[act]
-            model = np.where(_popcount64(am) % np.uint64(2) == 0, p0, p1).astype(np.uint64)  # mcts.rs:70-76
-            # unique (model, position) rows and the inverse map: lexsort + run boundaries
-            order = np.lexsort((av, am, model))
-            sm, sv, so = am[order], av[order], model[order]
-            first = np.ones(order.size, dtype=bool)
-            first[1:] = (sm[1:] != sm[:-1]) | (sv[1:] != sv[:-1]) | (so[1:] != so[:-1])
-            uniq = np.stack([so[first], sm[first], sv[first]], axis=1)
-            inv = np.empty(order.size, dtype=np.int64)
-            inv[order] = np.cumsum(first) - 1
-            ulp = np.zeros((uniq.shape[0], 7), dtype=np.float32)
-            uq = np.zeros((uniq.shape[0], 2), dtype=np.float32)
-            for mid in np.unique(uniq[:, 0]):
-                rows = np.nonzero(uniq[:, 0] == mid)[0]
-                for i in range(0, rows.size, self.cap):
-                    r = rows[i:i + self.cap]
-                    batch = _planes_from_bits(uniq[r, 1], uniq[r, 2])
-                    out = self.cb(int(mid), batch)
+        s, C = self.s, self._C
+        self._check(s.L.c4_session_leaf_keys(s._h, C.c_void_p(self.keys.data_ptr())))
+        if self.multi:   # group by model first: rows sort as (model, position)
+            rows = torch.stack([torch.where(self.keys >= 0, self.slot_models, torch.full_like(self.keys, -1)), self.keys], dim=1)
+            uniq, inv = torch.unique(rows, dim=0, return_inverse=True)
+            u_models, u_keys = uniq[:, 0], uniq[:, 1]
+        else:
+            u_keys, inv = torch.unique(self.keys, return_inverse=True)
+            u_models = None
+        n_u = u_keys.shape[0]
+        # any slot holding a unique position stands for it: take its row of the evaluator input
+        first = torch.empty(n_u, dtype=torch.int64, device=s.device).scatter_(0, inv, self.arange)
+        self.h_planes[:n_u].copy_(s.planes.index_select(0, first), non_blocking=True)
+        keys_h = u_keys.cpu().numpy()              # synchronises: the rows above have landed too
+        live = keys_h >= 0                         # idle slots share the key -1
+        if live.any():
+            models_h = u_models.cpu().numpy() if self.multi else None
+            planes_np, out_np = self.h_planes.numpy(), self.h_out.numpy()
+            # runs of one model (rows are sorted by model, then position), without the idle row
+            if self.multi:
+                cuts = np.flatnonzero(np.diff(models_h)) + 1
+                groups = [(int(a), int(b)) for a, b in zip(np.concatenate([[0], cuts]), np.concatenate([cuts, [n_u]]))]
+            else:
+                groups = [(0, n_u)]
+            for lo, hi_model in groups:
+                while lo < hi_model and not live[lo]:
+                    lo += 1
+                if lo >= hi_model:
+                    continue
+                mid = int(np.uint64(models_h[lo])) if self.multi else int(self.models_used[0])
+                for i in range(lo, hi_model, self.cap):
+                    j = min(i + self.cap, hi_model)
+                    out = self.cb(mid, planes_np[i:j])
                     if not (isinstance(out, (tuple, list)) and len(out) == 3):
                         raise TypeError("py_eval_pos_cb must return (policy_logprobs, q_penalty, q_no_penalty)")
                     lp, qp, qn = (np.asarray(a) for a in out)
-                    for name, a, shape in (("policy", lp, (r.size, 7)), ("q_penalty", qp, (r.size,)), ("q_no_penalty", qn, (r.size,))):
+                    for name, a, shape in (("policy", lp, (j - i, 7)), ("q_penalty", qp, (j - i,)), ("q_no_penalty", qn, (j - i,))):
                         # pybridge.rs:175-188: contiguous float32 arrays of the batch's shape
                         if a.dtype != np.float32 or a.shape != shape or not a.flags["C_CONTIGUOUS"]:
                             raise TypeError(f"py_eval_pos_cb: {name} must be C-contiguous float32 of shape {shape}, got {a.dtype} {a.shape}")
-                    ulp[r], uq[r, 0], uq[r, 1] = lp, qp, qn
-                    self.nn_positions += r.size
-            self.lp[act], self.q[act] = ulp[inv], uq[inv]
-        dev = self.s.device
-        self.s.logprobs.copy_(torch.from_numpy(self.lp).to(dev, non_blocking=False))
-        self.s.q.copy_(torch.from_numpy(self.q).to(dev, non_blocking=False))
-        return self.s.logprobs, self.s.q
+                    out_np[i:j, :7], out_np[i:j, 7], out_np[i:j, 8] = lp, qp, qn
+                    self.nn_positions += j - i
+            self.d_out[:n_u].copy_(self.h_out[:n_u], non_blocking=True)
+            fan = self.d_out.index_select(0, inv)            # unique answers -> every slot that asked
+            s.logprobs.copy_(fan[:, :7])
+            s.q.copy_(fan[:, 7:9])
+        return s.logprobs, s.q
 
 
 class _MultiModelEvaluator:
@@ -240,7 +270,7 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
         elif evaluator is None:
             p0 = np.array([r.player0_id for r in reqs], dtype=np.uint64)
             p1 = np.array([r.player1_id for r in reqs], dtype=np.uint64)
-            ev = _CallbackEvaluator(sessions[0], py_eval_pos_cb, max_nn_batch_size, lambda o: (p0[o], p1[o]))
+            ev = _CallbackEvaluator(sessions[0], py_eval_pos_cb, max_nn_batch_size, p0, p1)
             steps = sessions[0].run(ev, poll_every=1)
         elif multi:
             steps = sessions[0].run(_MultiModelEvaluator(sessions[0], evaluator))

@@ -53,6 +53,15 @@ C4_DEV uint32_t terminal_state(uint64_t mask, uint64_t value) {
   return 0;
 }
 
+// terminal_state of a position reached by a legal move FROM A NON-TERMINAL POSITION: no four existed
+// before the move and the mover's new piece belongs to the opponent of the side now to move, so
+// PlayerWin is impossible and only the opponent's stones need the four-in-a-row test.
+C4_DEV uint32_t terminal_after_move(uint64_t mask, uint64_t value) {
+  if (has_four(mask & ~value)) return 2;
+  if (__popcll(mask) == 42) return 3;
+  return 0;
+}
+
 // c4r.rs:253-263
 C4_DEV void terminal_value(uint32_t t, uint64_t mask, float c_ply_penalty, float& q_pen, float& q_nopen) {
   float mag = c_ply_penalty * (float)__popcll(mask);

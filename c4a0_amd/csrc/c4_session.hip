@@ -70,7 +70,7 @@ struct __attribute__((aligned(256))) Slot {
   uint32_t root_ref;    // (block << 3 | column) of the root's own entry
   uint32_t root_block;  // the root's children block, 0 = root not expanded
   uint32_t root_n;      // mirror of the root entry's visit count
-  uint32_t depth;       // leaf depth below the root; path[depth] = the leaf's entry
+  uint32_t depth;       // bits 0..7: leaf depth below the root, path[depth] = the leaf's entry; bits 8..9: terminal_state of the leaf
   uint32_t n_blocks;    // bump pointer of this slot's arena
   uint32_t n_moves;     // MctsGame::moves.len()
   uint32_t leaf_ref;    // = path[depth], kept in the header so the first line carries it
@@ -141,6 +141,8 @@ struct Params {
   uint2* cache;                   // optional evaluation cache (extension): [cache_mask + 1] entries of 64 bytes, 8 x uint2
   uint32_t cache_mask;
   uint32_t max_sims;              // simulations one game may run in one launch (terminal / cached leaves need no evaluator)
+  const float* ln_tab;            // ln_tab[k] = c4_logf((float)k), k < n_ln: the parent-visit term of uct_value (mcts.rs:379)
+  uint32_t n_ln;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -222,32 +224,35 @@ C4_DEV bool cache_lookup(const uint2* cache, uint32_t cache_mask, uint64_t mask,
   return hit;
 }
 
+// ln(visit count) of uct_value (mcts.rs:379): visit counts are small integers, so the glibc logf port's
+// result is read from a table filled by that same port at session creation (L1-resident: 4 bytes per
+// count); counts beyond the table (reference KATs with tens of thousands of iterations) compute it.
+C4_DEV float ln_visits(const Params& p, uint32_t n) {
+  return n < p.n_ln ? p.ln_tab[n] : c4::c4_logf((float)n);
+}
+
 // select_new_leaf (mcts.rs:160-183) for one game on its 8 lanes: from the root down to the first
-// unexpanded node, replaying make_move, recording the path (entry refs) in the slot and -- for the
-// backup of a same-launch simulation -- in the lanes (lane `sub` keeps levels sub and sub + 8).
+// unexpanded node, replaying make_move, recording the path (entry refs) in the lanes: lane `sub`
+// keeps levels sub, sub + 8 and sub + 16 (deeper levels go straight to the slot's path array).
 // Returns 0 or C4_ERR_NAN_IN_TREE.
-C4_DEV uint32_t select_leaf(const Block* blocks, Slot* st, uint64_t rmask, uint64_t rvalue, uint32_t root_block,
+C4_DEV uint32_t select_leaf(const Params& p, const Block* blocks, Slot* st, uint64_t rmask, uint64_t rvalue, uint32_t root_block,
                             uint32_t root_ref, uint32_t root_n, float c_exploration, uint32_t sub, int gbase,
                             uint64_t& leaf_mask, uint64_t& leaf_value, uint32_t& depth, uint32_t& leaf_ref,
-                            uint32_t& path_a, uint32_t& path_b, unsigned long long& levels) {
+                            uint32_t& path_a, uint32_t& path_b, uint32_t& path_c, uint32_t& levels) {
   uint64_t m = rmask, v = rvalue;
   uint32_t blk = root_block, d = 0, last_ref = root_ref;
-  float ln_np = c4::c4_logf((float)root_n);               // ln(parent visits) of the level being scored
+  float ln_np = ln_visits(p, root_n);                     // ln(parent visits) of the level being scored
   path_a = (sub == 0) ? root_ref : path_a;                // level 0 of the path = the root's own entry
   while (blk != 0 && d + 1 < kMaxPath) {
     const uint4 ce = load_block_lane(blocks, blk, sub);   // {n, q_pen, q_nopen, prior} | tail
-    // Off the dependent chain: every lane fetches ITS child's link out of the tail (lane 7) and
-    // takes ln of ITS child's visit count -- the parent term of the next level if that child wins.
-    const uint32_t t0 = shfl_u32(ce.x, gbase + 7), t1 = shfl_u32(ce.y, gbase + 7);
-    const uint32_t t2 = shfl_u32(ce.z, gbase + 7), t3 = shfl_u32(ce.w, gbase + 7);
-    const uint32_t tw = (sub >> 1) == 0 ? t0 : ((sub >> 1) == 1 ? t1 : ((sub >> 1) == 2 ? t2 : t3));
-    const uint32_t my_link = (tw >> (16u * (sub & 1u))) & 0xFFFFu;
-    const float my_ln = c4::c4_logf((float)ce.x);
+    // off the dependent chain: ln of THIS lane's child's visit count -- the parent term of the next
+    // level if that child wins (lane 7 holds the tail, not an entry)
+    const float my_ln = ln_visits(p, sub < 7 ? ce.x : 0u);
     const uint32_t legal = c4::legal_mask(m);
     const bool ok = sub < 7 && ((legal >> sub) & 1u);
     float score = 0.0f;
     if (ok) {
-      // uct_value (mcts.rs:359-388); c4_logf(1) == 0 makes every first-level score -0+0
+      // uct_value (mcts.rs:359-388); ln(1) == 0 makes every first-level score -0+0
       const float nf = (float)ce.x + 1.0f;
       const float qv = __uint_as_float(ce.y) / nf;
       float ex = ln_np / nf;
@@ -260,30 +265,33 @@ C4_DEV uint32_t select_leaf(const Block* blocks, Slot* st, uint64_t rmask, uint6
     const bool isn = ok && (score != score);
     const unsigned long long nan_ballot = __ballot(isn) >> gbase & 0xFFull;
     if (nan_ballot && __popc(legal) >= 2) return C4_ERR_NAN_IN_TREE;
-    // argmax over the group; the winner's visit count, link and ln travel with it
-    float bs = score, bln = my_ln;
-    int bi = ok ? (int)sub : -1;
-    uint32_t bn = ce.x, bl = my_link;
-#define C4_ARGMAX_STEP(K)                                                                        \
-    {                                                                                        \
-      const float os = grp_xchg<K>(bs), oln = grp_xchg<K>(bln);                              \
-      const int oi = (int)grp_xchg<K>((uint32_t)bi);                                         \
-      const uint32_t on = grp_xchg<K>(bn), ol = grp_xchg<K>(bl);                             \
-      const bool take = (oi >= 0) && (bi < 0 || os > bs || (os == bs && oi > bi));           \
-      bs = take ? os : bs; bi = take ? oi : bi; bn = take ? on : bn;                         \
-      bl = take ? ol : bl; bln = take ? oln : bln;                                           \
+    // Argmax as the maximum of a 64-bit key: high word = the score mapped monotonically onto
+    // unsigned integers (-0 first folded into +0: the two compare equal as floats), low word =
+    // column + 1, so equal scores go to the LAST column and a lane without a legal move (key 0)
+    // never wins.  Three DPP exchanges, one 64-bit compare each.
+    const uint32_t sbits = __float_as_uint(score + 0.0f);
+    const uint32_t ord = sbits ^ ((uint32_t)((int32_t)sbits >> 31) | 0x80000000u);
+    unsigned long long key = ok ? (((unsigned long long)ord << 32) | (sub + 1u)) : 0ull;
+#define C4_KEYMAX_STEP(K)                                                                                          \
+    {                                                                                                          \
+      const unsigned long long o = ((unsigned long long)grp_xchg<K>((uint32_t)(key >> 32)) << 32) | grp_xchg<K>((uint32_t)key); \
+      key = o > key ? o : key;                                                                                 \
     }
-    C4_ARGMAX_STEP(0) C4_ARGMAX_STEP(1) C4_ARGMAX_STEP(2)
-#undef C4_ARGMAX_STEP
-    const uint32_t best = (uint32_t)bi;
-    ln_np = bln;
-    const uint32_t next_blk = bl;
+    C4_KEYMAX_STEP(0) C4_KEYMAX_STEP(1) C4_KEYMAX_STEP(2)
+#undef C4_KEYMAX_STEP
+    const uint32_t best = (uint32_t)key - 1u;
+    // the winner's ln (next level's parent term) and its child link (out of the tail, lane 7)
+    ln_np = shfl_f32(my_ln, gbase + (int)best);
+    const uint32_t w = best >> 1;
+    const uint32_t tw = w == 0 ? ce.x : (w == 1 ? ce.y : (w == 2 ? ce.z : ce.w));
+    const uint32_t next_blk = (shfl_u32(tw, gbase + 7) >> (16u * (best & 1u))) & 0xFFFFu;
     c4::make_move(m, v, best);
     d += 1;
     last_ref = (blk << 3) | best;
-    if (sub == 0) st->path[d] = last_ref;
-    path_a = (d == sub) ? last_ref : path_a;               // the lanes keep their own backup levels
+    path_a = (d == sub) ? last_ref : path_a;               // the lanes keep the path
     path_b = (d == sub + 8) ? last_ref : path_b;
+    path_c = (d == sub + 16) ? last_ref : path_c;
+    if (d >= 24 && sub == 0) st->path[d] = last_ref;       // rare: beyond what the lanes hold
     blk = next_blk;
     levels += 1;
   }
@@ -307,6 +315,41 @@ C4_DEV void store_plane<uint16_t>(void* base, size_t idx, uint32_t bit) {
   ((uint16_t*)base)[idx] = bit ? (uint16_t)0x3F80 : (uint16_t)0;  // bf16 1.0 / 0.0
 }
 
+// A game's leaf as the evaluator's input row (c4r.rs:378-392): 84 elements, plane 0 = the bits of
+// `value`, plane 1 = the opponent's pieces, in bit order.  bf16: the 84-bit string value | opp << 42 is
+// cut into bytes, lane `sub` expands byte `sub` (and, lanes 0..2, the bits 64..83) into eight bf16 0/1
+// and writes them with one 16-byte store -- two store instructions per game instead of eleven.
+template <typename PlaneT>
+C4_DEV void encode_leaf(void* planes, uint32_t g, uint64_t mask, uint64_t value, uint32_t sub);
+template <>
+C4_DEV void encode_leaf<float>(void* planes, uint32_t g, uint64_t mask, uint64_t value, uint32_t sub) {
+  for (uint32_t e = sub; e < C4_PLANES_LEN; e += 8) store_plane<float>(planes, (size_t)g * C4_PLANES_LEN + e, c4::plane_bit(mask, value, e));
+}
+C4_DEV uint4 bf16_bits8(uint32_t byte) {   // bit j of `byte` -> bf16 1.0 / 0.0 in element j
+  uint4 r;
+  r.x = ((byte >> 0) & 1u) * 0x3F80u + ((byte >> 1) & 1u) * 0x3F800000u;
+  r.y = ((byte >> 2) & 1u) * 0x3F80u + ((byte >> 3) & 1u) * 0x3F800000u;
+  r.z = ((byte >> 4) & 1u) * 0x3F80u + ((byte >> 5) & 1u) * 0x3F800000u;
+  r.w = ((byte >> 6) & 1u) * 0x3F80u + ((byte >> 7) & 1u) * 0x3F800000u;
+  return r;
+}
+template <>
+C4_DEV void encode_leaf<uint16_t>(void* planes, uint32_t g, uint64_t mask, uint64_t value, uint32_t sub) {
+  const uint64_t opp = mask & ~value;
+  const uint64_t lo = value | (opp << 42);          // elements 0..63
+  const uint32_t hi = (uint32_t)(opp >> 22);        // elements 64..83
+  uint16_t* row = (uint16_t*)planes + (size_t)g * C4_PLANES_LEN;
+  const uint4 a = bf16_bits8((uint32_t)(lo >> (8u * sub)) & 0xFFu);
+  // rows are 168 bytes apart: 8-byte aligned, so the 16 bytes go out as two 8-byte stores
+  reinterpret_cast<uint2*>(row + 8 * sub)[0] = make_uint2(a.x, a.y);
+  reinterpret_cast<uint2*>(row + 8 * sub)[1] = make_uint2(a.z, a.w);
+  if (sub < 3) {
+    const uint4 b = bf16_bits8((hi >> (8u * sub)) & 0xFFu);
+    reinterpret_cast<uint2*>(row + 64 + 8 * sub)[0] = make_uint2(b.x, b.y);
+    if (sub < 2) reinterpret_cast<uint2*>(row + 64 + 8 * sub)[1] = make_uint2(b.z, b.w);
+  }
+}
+
 // MctsGame::leaf_model_id_to_play (mcts.rs:70-76): player 0's model on even plies, player 1's on odd.
 C4_DEV void publish_leaf_model(const Params& p, uint32_t g, unsigned long long ordinal, uint64_t leaf_mask) {
   if (p.leaf_models) {
@@ -328,7 +371,8 @@ C4_DEV void reset_slot(const Params& p, Slot* st, Block* blocks, uint32_t sub, u
     st->ordinal = (uint32_t)ordinal;
     st->status = kActive;
     st->root_ref = 0; st->root_block = 0; st->root_n = 0;
-    st->depth = 0; st->n_blocks = 1; st->n_moves = 0;
+    st->depth = c4::terminal_state(m, v) << 8;   // the start position may be anything, terminal included
+    st->n_blocks = 1; st->n_moves = 0;
     st->leaf_ref = 0;
     st->rng_for = 0;
     st->path[0] = 0;
@@ -365,15 +409,22 @@ __global__ __launch_bounds__(64) void c4_start_kernel(Params p) {
 //   -> gate / move / finish / refill (self_play.rs:283-308, mcts.rs:187-222, 271-313)
 //   -> select (mcts.rs:160-183)  ->  encode the new leaf (c4r.rs:378-392)
 // ------------------------------------------------------------------------------------------
+// Wavefronts per SIMD the default instantiation is compiled for.  Measured (tools/tree_roofline.py):
+// 4 (127 registers, no spill) and 3 run alike up to 65 536 games per launch and 4 is 8 % slower at
+// 131 072; 5 (96 registers, spills) is 20 % slower: the kernel is not occupancy-bound.  The
+// extension instantiations keep what they need.
+#ifndef C4_STEP_WAVES
+#define C4_STEP_WAVES 3
+#endif
 template <typename PlaneT, bool NOISE, bool CACHE>
-__global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
+__global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_step_kernel(Params p) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t sub = lane & 7;
   const int gbase = (int)(lane & ~7u);
   const uint32_t g = blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
 
-  unsigned long long c_sims = 0, c_S = 0, c_K = 0, c_E = 0, c_moves = 0, c_done = 0, c_skipped = 0, c_samples = 0;
-  unsigned long long c_probes = 0, c_hits = 0;
+  uint32_t c_sims = 0, c_S = 0, c_K = 0, c_E = 0, c_moves = 0, c_done = 0, c_skipped = 0, c_samples = 0;   // this launch only
+  uint32_t c_probes = 0, c_hits = 0;
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz device clock
   C4_STAMP(0, 0);
 #ifdef C4_PHASE_STAMPS
@@ -415,6 +466,8 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     uint64_t leaf_mask = st->leaf_mask, leaf_value = st->leaf_value;
     uint64_t rmask = st->root_mask, rvalue = st->root_value;
     uint32_t depth = st->depth;
+    uint32_t term = depth >> 8;          // terminal_state of the waiting leaf, computed when it was selected
+    depth &= 0xFFu;
     uint32_t n_blocks = st->n_blocks;
     uint32_t root_ref = st->root_ref;
     uint32_t root_block = st->root_block;
@@ -428,6 +481,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     // so these loads go out together with the header
     uint32_t path_a = st->path[sub];
     uint32_t path_b = st->path[sub + 8];
+    uint32_t path_c = st->path[sub + 16];
     uint32_t err = 0;
     uint32_t root_n = 0;
     // One simulation per game per launch, plus a second one when the leaf just selected is terminal:
@@ -448,7 +502,6 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     for (uint32_t sim = 0; sim < max_sims; sim++) {
       // ---------------- on_received_policy: terminal value or expansion -------------------
       float v_pen, v_nopen;
-      const uint32_t term = c4::terminal_state(leaf_mask, leaf_value);
       if (term) {
         c4::terminal_value(term, leaf_mask, p.c_ply_penalty, v_pen, v_nopen);  // NN output ignored (mcts.rs:92-98)
       } else {
@@ -500,7 +553,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       // ---------------- backpropagate_value: leaf -> root along the recorded path ----------
       root_n = 0;
       for (uint32_t d = sub; d <= depth; d += 8) {
-        const uint32_t ref = (d < 8) ? path_a : (d < 16 ? path_b : st->path[d]);
+        const uint32_t ref = (d < 8) ? path_a : (d < 16 ? path_b : (d < 24 ? path_c : st->path[d]));
         Entry* e = &blocks[ref >> 3].e[ref & 7];
         const bool odd = ((depth - d) & 1u) != 0;                             // value negated per step up
         const uint32_t n1 = e->n + 1;
@@ -514,9 +567,12 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       root_n = shfl_u32(root_n, gbase);
       c_sims += 1;
       c_K += depth + 1;
-      // stores above are read back below through other lanes of this wave
+      // The stores above are read back below through other lanes of THIS wavefront.  A wavefront's
+      // vector-memory instructions reach the cache in program order, so a later load of the same
+      // address returns the stored bytes without waiting for the store's acknowledgement: only the
+      // compiler must not reorder them (a wavefront-scope fence emits no instruction).
       C4_STAMP_TRIP1(3, root_n);
-      __threadfence_block();
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       C4_STAMP_TRIP1(4, root_n);
 
       // ---------------- gate: self_play.rs:283-308 ------------------------------------------
@@ -565,7 +621,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
             c4::make_move(rmask, rvalue, (uint32_t)col);
             n_moves += 1;
             c_moves += 1;
-            rterm = c4::terminal_state(rmask, rvalue);
+            rterm = c4::terminal_after_move(rmask, rvalue);   // the position moved from was not terminal
             if (NOISE && p.dir_eps > 0.0f && !rterm && root_block != 0) {
               // extension: the new root keeps its subtree; fresh noise goes into its children's priors
               const uint32_t nlegal = c4::legal_mask(rmask);
@@ -579,7 +635,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
                 const float add = p.dir_eps * mine;
                 ce->prior = keep + add;
               }
-              __threadfence_block();
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             }
           }
         }
@@ -622,7 +678,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
         next = ((unsigned long long)shfl_u32((uint32_t)(next >> 32), gbase) << 32) | shfl_u32((uint32_t)next, gbase);
         if (next < p.n_games) {
           reset_slot(p, st, blocks, sub, next);
-          __threadfence_block();
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
           rmask = p.start_mask ? p.start_mask[next] : 0ull;
           rvalue = p.start_value ? p.start_value[next] : 0ull;
           root_ref = 0; root_block = 0; root_n = 0; n_blocks = 1; n_moves = 0;
@@ -637,22 +693,25 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
       }
       C4_STAMP_TRIP1(5, root_n);
       // ---------------- select_new_leaf (mcts.rs:160-183) -------------------------------
-      err = select_leaf(blocks, st, rmask, rvalue, root_block, root_ref, root_n, p.c_exploration, sub, gbase,
-                        leaf_mask, leaf_value, depth, leaf_ref, path_a, path_b, c_S);
+      err = select_leaf(p, blocks, st, rmask, rvalue, root_block, root_ref, root_n, p.c_exploration, sub, gbase,
+                        leaf_mask, leaf_value, depth, leaf_ref, path_a, path_b, path_c, c_S);
       if (err) break;
       C4_STAMP_TRIP1(6, depth);
       if (sim == 1) C4_STAMP_ANY(13);
+      // terminal_state of the new leaf (kept for the simulation that consumes it): below the root it was
+      // reached by a move from a non-terminal node; the root itself may be an arbitrary start position
+      term = depth == 0 ? c4::terminal_state(leaf_mask, leaf_value) : c4::terminal_after_move(leaf_mask, leaf_value);
       // a terminal leaf needs no evaluator, nor does one whose evaluation is in the cache: run that
       // simulation now, while trips remain
       if (sim + 1 < max_sims) {
-        bool again = c4::terminal_state(leaf_mask, leaf_value) != 0;
+        bool again = term != 0;
         if (CACHE && !again) {
           c_probes += 1;
           again = cache_lookup(p.cache, p.cache_mask, leaf_mask, leaf_value, cur_logit, cur_qp, cur_qn, sub, gbase);
           c_hits += again ? 1 : 0;
         }
         if (again) {
-          if (depth >= 16) __threadfence_block();              // levels >= 16 are re-read from the slot's path
+          if (depth >= 24) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // levels >= 24 are re-read from the slot's path
           continue;
         }
       }
@@ -667,17 +726,19 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
         st->root_mask = rmask; st->root_value = rvalue;
         st->leaf_mask = leaf_mask; st->leaf_value = leaf_value;
         st->root_ref = root_ref; st->root_block = root_block; st->root_n = root_n;
-        st->depth = depth; st->n_blocks = n_blocks; st->n_moves = n_moves;
-        st->path[0] = root_ref;
+        st->depth = depth | (term << 8); st->n_blocks = n_blocks; st->n_moves = n_moves;
         st->leaf_ref = leaf_ref;
         publish_leaf_model(p, g, ordinal, leaf_mask);
       }
+      // the recorded path goes back to the slot: lane `sub` holds levels sub, sub + 8, sub + 16
+      st->path[sub] = path_a;
+      if (depth >= 8) st->path[sub + 8] = path_b;
+      if (depth >= 16) st->path[sub + 16] = path_c;
       pre_need = fresh || (rng_for != n_moves + 1);   // after a move / refill the stored word is stale
       pre_n_moves = n_moves;
       pre_game_id = game_id;
       // ---------------- leaf -> evaluator input (c4r.rs:378-392) ----------------------
-      for (uint32_t e = sub; e < C4_PLANES_LEN; e += 8)
-        store_plane<PlaneT>(p.planes, (size_t)g * C4_PLANES_LEN + e, c4::plane_bit(leaf_mask, leaf_value, e));
+      encode_leaf<PlaneT>(p.planes, g, leaf_mask, leaf_value, sub);
     }
   }
 
@@ -686,7 +747,7 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
   // lane `sub` of each game adds that game's counter number `sub` to the wavefront's row: one
   // no-return atomic instruction for the whole wave (nobody waits for it; rows have one writer wave)
   {
-    unsigned long long add = c_sims;
+    uint32_t add = c_sims;
     add = sub == CTR_S ? c_S : add;
     add = sub == CTR_K ? c_K : add;
     add = sub == CTR_E ? c_E : add;
@@ -694,9 +755,9 @@ __global__ __launch_bounds__(64) void c4_step_kernel(Params p) {
     add = sub == CTR_DONE ? c_done : add;
     add = sub == CTR_SKIPPED ? c_skipped : add;
     add = sub == CTR_SAMPLES ? c_samples : add;
-    if (add) atomicAdd(&p.wave_ctr[(size_t)blockIdx.x * CTR_N + sub], add);
-    const unsigned long long add2 = sub == 0 ? c_probes : (sub == 1 ? c_hits : 0ull);
-    if (add2) atomicAdd(&p.wave_ctr[(size_t)blockIdx.x * CTR_N + CTR_PROBES + sub], add2);
+    if (add) atomicAdd(&p.wave_ctr[(size_t)blockIdx.x * CTR_N + sub], (unsigned long long)add);
+    const uint32_t add2 = sub == 0 ? c_probes : (sub == 1 ? c_hits : 0u);
+    if (CACHE && add2) atomicAdd(&p.wave_ctr[(size_t)blockIdx.x * CTR_N + CTR_PROBES + sub], (unsigned long long)add2);
   }
   // ---------------- move RNG, off the critical path ------------------------------------------
   // The launch lasts as long as its slowest wavefront, and that is one with a MOVING game.  The
@@ -746,6 +807,12 @@ __global__ void k_encode(const uint64_t* mask, const uint64_t* value, uint64_t n
   const uint64_t g = i / C4_PLANES_LEN;
   const uint32_t e = (uint32_t)(i % C4_PLANES_LEN);
   store_plane<PlaneT>(planes, i, c4::plane_bit(mask[g], value[g], e));
+}
+
+// ln_tab[k] = c4_logf((float)k): the same port the kernel would otherwise run per tree level
+__global__ void k_ln_table(float* tab, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tab[i] = c4::c4_logf((float)i);
 }
 
 __global__ void k_expf_logf(const float* x, uint64_t n, int which, float* y) {
@@ -873,6 +940,24 @@ __global__ __launch_bounds__(1024) void k_sample_offsets(const uint32_t* counts,
   if (tid == 0) *total = carry;
 }
 
+// Leaf keys for the callback evaluator's batching (NNThread::loop_once, self_play.rs:203-208: unique
+// (model, leaf position) pairs).  A position is its `value` bits (42) plus the 7 column heights
+// (3 bits each: the stones of a column stack from the bottom, so the heights determine `mask`):
+// 63 bits, one non-negative int64 per resident game; idle slots get -1.
+__global__ void k_leaf_keys(const Slot* slots, uint32_t n_slots, long long* keys) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_slots) return;
+  const Slot* st = slots + g;
+  long long key = -1;
+  if (st->status == kActive) {
+    const uint64_t m = st->leaf_mask, v = st->leaf_value;
+    uint64_t heights = 0;
+    for (uint32_t c = 0; c < 7; c++) heights |= (uint64_t)__popcll(m & (c4::kCol0 << c)) << (3 * c);
+    key = (long long)(v | (heights << 42));
+  }
+  keys[g] = key;
+}
+
 // K6: pack finished games' records contiguously (one wavefront per game, 4 records per pass)
 __global__ __launch_bounds__(64) void k_pack_samples(const c4_sample_rec* src, const uint32_t* counts,
                                                      const unsigned long long* offsets, uint64_t n_games, c4_sample_rec* dst) {
@@ -931,6 +1016,7 @@ struct c4_session {
   uint32_t probe_error = 0;
   CompactPlan* plan_dev = nullptr;   // tail compaction scratch
   uint2* pairs_dev = nullptr;
+  float* ln_tab_dev = nullptr;                 // ln(visit count) table of select (Params::ln_tab)
   unsigned long long* offsets_dev = nullptr;   // pack_samples: [n_games] record offsets + [1] total, sized by set_games
   unsigned long long* total_host = nullptr;    // pinned
 };
@@ -973,6 +1059,10 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   p.c_ply_penalty = cfg->c_ply_penalty;
   p.flags = cfg->flags;
   p.max_sims = (cfg->flags & (C4_FLAG_NO_MOVES | C4_FLAG_ONE_SIM_PER_STEP)) ? 1u : 2u;
+  // visit counts stay below n_mcts_iterations + 1 in self-play (the gate); the table covers them with
+  // room to spare, larger counts (C4_FLAG_NO_MOVES runs) take the computed path
+  uint32_t n_ln = cfg->n_mcts_iterations + 64u;
+  n_ln = n_ln < 1024u ? 1024u : (n_ln > 65536u ? 65536u : n_ln);
   hipError_t e;
   if ((e = hipMalloc(&p.slots, n * sizeof(Slot))) != hipSuccess ||
       (e = hipMalloc(&p.blocks, n * bps * sizeof(Block))) != hipSuccess ||
@@ -981,11 +1071,17 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
       (e = hipMalloc(&p.stamps, (size_t)s->n_waves * 4 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.clock_acc, 2 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.phase, (size_t)s->n_waves * 16 * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMalloc(&s->ln_tab_dev, (size_t)n_ln * sizeof(float))) != hipSuccess ||
       (e = hipHostMalloc(&s->probe_host, sizeof(Globals))) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s->probe_event, hipEventDisableTiming)) != hipSuccess)
     return fail(C4_ERR_HIP, std::string("allocating session (") + std::to_string((n * bps * sizeof(Block)) >> 20) +
                                 " MiB of tree arena): " + hipGetErrorString(e));
   p.n_waves = s->n_waves;
+  p.ln_tab = s->ln_tab_dev;
+  p.n_ln = n_ln;
+  hipLaunchKernelGGL(k_ln_table, dim3((n_ln + 255) / 256), dim3(256), 0, nullptr, s->ln_tab_dev, n_ln);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(p.stamps, 0, (size_t)s->n_waves * 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(p.clock_acc, 0, 2 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(p.phase, 0, (size_t)s->n_waves * 16 * sizeof(unsigned long long)));
@@ -1024,7 +1120,7 @@ int c4_session_destroy(c4_session* s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream); else (void)hipDeviceSynchronize();
   (void)hipFree(s->p.slots); (void)hipFree(s->p.blocks); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob); (void)hipFree(s->p.stamps); (void)hipFree(s->p.clock_acc); (void)hipFree(s->p.phase);
   (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts); (void)hipFree(s->p.cache);
-  (void)hipFree(s->plan_dev); (void)hipFree(s->pairs_dev); (void)hipFree(s->offsets_dev);
+  (void)hipFree(s->plan_dev); (void)hipFree(s->pairs_dev); (void)hipFree(s->offsets_dev); (void)hipFree(s->ln_tab_dev);
   if (s->total_host) (void)hipHostFree(s->total_host);
   (void)hipFree(s->reqs_dev); (void)hipFree(s->start_mask_dev); (void)hipFree(s->start_value_dev);
   if (s->probe_host) (void)hipHostFree(s->probe_host);
@@ -1374,6 +1470,14 @@ int c4_session_root_stats(c4_session* s, uint32_t slot, float policy[7], float* 
     for (int c = 0; c < 7; c++) sum = sum + cnt[c];
     for (int c = 0; c < 7; c++) policy[c] = (sum == 0.0f) ? (1.0f / 7.0f) : cnt[c] / sum;
   }
+  return C4_OK;
+}
+
+int c4_session_leaf_keys(c4_session* s, int64_t* keys_dev) {
+  if (!s || !keys_dev) return fail(C4_ERR_BAD_ARG, "null argument");
+  C4_ON_DEVICE(s->cfg.device);
+  hipLaunchKernelGGL(k_leaf_keys, dim3((s->cfg.n_slots + 255) / 256), dim3(256), 0, s->stream, s->p.slots, s->cfg.n_slots, (long long*)keys_dev);
+  HIP_TRY(hipGetLastError());
   return C4_OK;
 }
 

@@ -206,6 +206,13 @@ int c4_session_sample_store(c4_session* s, const c4_sample_rec** recs_dev, const
  * root_q_no_penalty / root_visit_count, mcts.rs:248-268).  Synchronises. */
 int c4_session_root_stats(c4_session* s, uint32_t slot, float policy[7], float* q_penalty,
                           float* q_no_penalty, uint64_t* visit_count, uint64_t* root_mask, uint64_t* root_value);
+/* One int64 per slot identifying the leaf position waiting for the evaluator (value bits | the 7
+ * column heights << 42; -1 for an idle slot), written to the DEVICE array keys_dev[n_slots] on the
+ * session's stream, no synchronisation.  The callback evaluator sorts these on the device to find
+ * the unique positions of a batch (NNThread::loop_once's HashSet, self_play.rs:203-208) instead of
+ * copying every slot to the host. */
+int c4_session_leaf_keys(c4_session* s, int64_t* keys_dev);
+
 /* Leaf position currently waiting for the evaluator, per slot (MctsGame::leaf_pos, mcts.rs:64-66);
  * status[g] = 1 active / 0 idle, ordinal[g] = index of the slot's game in reqs.  Host arrays of
  * n_slots (any may be NULL).  Synchronises.  Used by the numpy-callback compatibility mode. */
