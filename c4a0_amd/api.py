@@ -271,7 +271,7 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
             p0 = np.array([r.player0_id for r in reqs], dtype=np.uint64)
             p1 = np.array([r.player1_id for r in reqs], dtype=np.uint64)
             ev = _CallbackEvaluator(sessions[0], py_eval_pos_cb, max_nn_batch_size, p0, p1)
-            steps = sessions[0].run(ev, poll_every=1)
+            steps = sessions[0].run(ev, poll_every=4)   # the completion probe every 4th step: at most 3 idle steps at the very end
         elif multi:
             steps = sessions[0].run(_MultiModelEvaluator(sessions[0], evaluator))
         else:

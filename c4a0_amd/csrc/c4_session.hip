@@ -24,8 +24,10 @@
 // compiled with -ffp-contract=off (see build.py) and uses the glibc expf/logf ports.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -61,24 +63,39 @@ struct __attribute__((aligned(128))) Block {
 constexpr uint32_t kMaxBlocksPerSlot = 65535;
 
 constexpr uint32_t kMaxPath = 43;   // root + at most 42 moves below it
+constexpr uint32_t kHotPath = 16;   // path levels kept in the slot's hot line
+// A resident game's state.  Everything a simulation needs is ONE 128-byte line, read by the game's
+// 8 lanes with one 16-byte-per-lane instruction at the start of the step kernel and written back
+// with one at the end (lane k owns dwords 4k..4k+3):
+//   lane 0: root position          lane 1: leaf position (waiting for the evaluator)
+//   lane 2: game id, ordinal, root visit count
+//   lane 3: state word, arena words, root ref, precomputed move RNG word
+//   lanes 4..7: the recorded path, TRANSPOSED: lane 4 + j holds levels j, j + 4, j + 8, j + 12, so
+//               the backup of level d runs on lane 4 + (d & 3) and the first four levels update in parallel
+// The second line holds path levels 16..42 (deep searches only).
 struct __attribute__((aligned(256))) Slot {
   uint64_t root_mask, root_value;  // MctsGame::root position
-  uint64_t leaf_mask, leaf_value;  // MctsGame::leaf position (waiting for the evaluator)
+  uint64_t leaf_mask, leaf_value;  // MctsGame::leaf position
   uint64_t game_id;
   uint32_t ordinal;     // index into reqs / the sample store
-  uint32_t status;      // 0 idle, 1 active, >1 = c4_status error
-  uint32_t root_ref;    // (block << 3 | column) of the root's own entry
-  uint32_t root_block;  // the root's children block, 0 = root not expanded
   uint32_t root_n;      // mirror of the root entry's visit count
-  uint32_t depth;       // bits 0..7: leaf depth below the root, path[depth] = the leaf's entry; bits 8..9: terminal_state of the leaf
-  uint32_t n_blocks;    // bump pointer of this slot's arena
-  uint32_t n_moves;     // MctsGame::moves.len()
-  uint32_t leaf_ref;    // = path[depth], kept in the header so the first line carries it
+  uint32_t state;       // status[0:8] (0 idle, 1 active, >1 = c4_status error) | depth[8:16] (path[depth] = the leaf's entry)
+                        // | n_moves[16:24] | terminal_state of the leaf [24:26] | rng_for[26:32] (n_moves + 1 rng_word is for; 0 = none)
+  uint32_t arena;       // n_blocks[0:16] (bump pointer) | root_block[16:32] (the root's children block, 0 = not expanded)
+  uint32_t root_ref;    // (block << 3 | column) of the root's own entry
   uint32_t rng_word;    // first ChaCha12 word for the NEXT move (mcts.rs:215-216), precomputed off the critical path
-  uint32_t rng_for;     // n_moves + 1 the word was computed for; 0 = none
-  uint32_t path[kMaxPath];  // entry refs root..leaf written by select, consumed by backup
+  uint32_t path[kHotPath];        // entry refs of levels 0..15, transposed: path[4 * j + i] = level j + 4 * i
+  uint32_t path_deep[kMaxPath - kHotPath];   // levels 16..42
+  uint32_t pad_[32 - (kMaxPath - kHotPath)];
 };
-static_assert(sizeof(Slot) == 256, "slot state is two cache lines");
+static_assert(sizeof(Slot) == 256 && offsetof(Slot, path) == 64 && offsetof(Slot, path_deep) == 128, "slot state: one hot line + the deep path");
+C4_DEV constexpr uint32_t slot_state(uint32_t status, uint32_t depth, uint32_t n_moves, uint32_t term, uint32_t rng_for) {
+  return status | (depth << 8) | (n_moves << 16) | (term << 24) | (rng_for << 26);
+}
+C4_DEV uint32_t slot_status(uint32_t state) { return state & 0xFFu; }
+C4_DEV uint32_t& slot_path_ref(Slot* st, uint32_t level) {   // where level `level` of the path lives
+  return level < kHotPath ? st->path[4 * (level & 3u) + (level >> 2)] : st->path_deep[level - kHotPath];
+}
 static_assert(sizeof(Block) == 128 && sizeof(Entry) == 16 && sizeof(Tail) == 16 && sizeof(c4_sample_rec) == 64, "layout");
 
 enum : uint32_t { kIdle = 0, kActive = 1 };
@@ -224,6 +241,15 @@ C4_DEV bool cache_lookup(const uint2* cache, uint32_t cache_mask, uint64_t mask,
   return hit;
 }
 
+// Level `level` of the path a game's lanes hold (pv of lane 4 + j = levels j, j + 4, j + 8, j + 12),
+// for every lane of the group; levels beyond the hot line come from the slot's second line.
+C4_DEV uint32_t path_level(const uint4& pv, const Slot* st, uint32_t level, int gbase) {
+  const uint32_t c = (level >> 2) & 3u;
+  const uint32_t mine = c == 0 ? pv.x : (c == 1 ? pv.y : (c == 2 ? pv.z : pv.w));
+  const uint32_t hotv = shfl_u32(mine, gbase + 4 + (int)(level & 3u));
+  return level < kHotPath ? hotv : st->path_deep[level - kHotPath];
+}
+
 // ln(visit count) of uct_value (mcts.rs:379): visit counts are small integers, so the glibc logf port's
 // result is read from a table filled by that same port at session creation (L1-resident: 4 bytes per
 // count); counts beyond the table (reference KATs with tens of thousands of iterations) compute it.
@@ -232,17 +258,17 @@ C4_DEV float ln_visits(const Params& p, uint32_t n) {
 }
 
 // select_new_leaf (mcts.rs:160-183) for one game on its 8 lanes: from the root down to the first
-// unexpanded node, replaying make_move, recording the path (entry refs) in the lanes: lane `sub`
-// keeps levels sub, sub + 8 and sub + 16 (deeper levels go straight to the slot's path array).
-// Returns 0 or C4_ERR_NAN_IN_TREE.
+// unexpanded node, replaying make_move, recording the path (entry refs) in the lanes as the slot's
+// hot line keeps it: lane 4 + j holds levels j, j + 4, j + 8, j + 12 in pv[0..3] (deeper levels go
+// straight to the slot's second line).  Returns 0 or C4_ERR_NAN_IN_TREE.
 C4_DEV uint32_t select_leaf(const Params& p, const Block* blocks, Slot* st, uint64_t rmask, uint64_t rvalue, uint32_t root_block,
                             uint32_t root_ref, uint32_t root_n, float c_exploration, uint32_t sub, int gbase,
                             uint64_t& leaf_mask, uint64_t& leaf_value, uint32_t& depth, uint32_t& leaf_ref,
-                            uint32_t& path_a, uint32_t& path_b, uint32_t& path_c, uint32_t& levels) {
+                            uint4& pv, uint32_t& levels) {
   uint64_t m = rmask, v = rvalue;
   uint32_t blk = root_block, d = 0, last_ref = root_ref;
   float ln_np = ln_visits(p, root_n);                     // ln(parent visits) of the level being scored
-  path_a = (sub == 0) ? root_ref : path_a;                // level 0 of the path = the root's own entry
+  pv.x = (sub == 4) ? root_ref : pv.x;                    // level 0 of the path = the root's own entry
   while (blk != 0 && d + 1 < kMaxPath) {
     const uint4 ce = load_block_lane(blocks, blk, sub);   // {n, q_pen, q_nopen, prior} | tail
     // off the dependent chain: ln of THIS lane's child's visit count -- the parent term of the next
@@ -288,10 +314,15 @@ C4_DEV uint32_t select_leaf(const Params& p, const Block* blocks, Slot* st, uint
     c4::make_move(m, v, best);
     d += 1;
     last_ref = (blk << 3) | best;
-    path_a = (d == sub) ? last_ref : path_a;               // the lanes keep the path
-    path_b = (d == sub + 8) ? last_ref : path_b;
-    path_c = (d == sub + 16) ? last_ref : path_c;
-    if (d >= 24 && sub == 0) st->path[d] = last_ref;       // rare: beyond what the lanes hold
+    {                                                      // the lanes keep the path: level d on lane 4 + (d & 3)
+      const bool mine = sub == 4u + (d & 3u);
+      const uint32_t comp = d >> 2;
+      pv.x = (mine && comp == 0) ? last_ref : pv.x;
+      pv.y = (mine && comp == 1) ? last_ref : pv.y;
+      pv.z = (mine && comp == 2) ? last_ref : pv.z;
+      pv.w = (mine && comp == 3) ? last_ref : pv.w;
+    }
+    if (d >= kHotPath && sub == 0) st->path_deep[d - kHotPath] = last_ref;   // rare: beyond what the lanes hold
     blk = next_blk;
     levels += 1;
   }
@@ -300,7 +331,7 @@ C4_DEV uint32_t select_leaf(const Params& p, const Block* blocks, Slot* st, uint
 }
 
 C4_DEV void raise_error(const Params& p, Slot* st, uint32_t g, uint32_t code) {
-  st->status = code;
+  st->state = (st->state & ~0xFFu) | code;
   if (atomicCAS(&p.glob->error, 0u, code) == 0u) p.glob->error_slot = g;
 }
 
@@ -369,12 +400,11 @@ C4_DEV void reset_slot(const Params& p, Slot* st, Block* blocks, uint32_t sub, u
     st->leaf_mask = m; st->leaf_value = v;
     st->game_id = p.reqs[ordinal].game_id;
     st->ordinal = (uint32_t)ordinal;
-    st->status = kActive;
-    st->root_ref = 0; st->root_block = 0; st->root_n = 0;
-    st->depth = c4::terminal_state(m, v) << 8;   // the start position may be anything, terminal included
-    st->n_blocks = 1; st->n_moves = 0;
-    st->leaf_ref = 0;
-    st->rng_for = 0;
+    st->root_n = 0;
+    // the start position may be anything, terminal included: full terminal_state
+    st->state = slot_state(kActive, 0, 0, c4::terminal_state(m, v), 0);
+    st->arena = 1;            // n_blocks = 1, root not expanded
+    st->root_ref = 0;
     st->path[0] = 0;
   }
 }
@@ -397,7 +427,7 @@ __global__ __launch_bounds__(64) void c4_start_kernel(Params p) {
     v = p.start_value ? p.start_value[g] : 0ull;
     if (sub == 0) publish_leaf_model(p, g, g, m);
   } else if (sub == 0) {
-    st->status = kIdle;
+    st->state = kIdle;
     st->ordinal = 0xFFFFFFFFu;
   }
   for (uint32_t e = sub; e < C4_PLANES_LEN; e += 8) store_plane<PlaneT>(p.planes, (size_t)g * C4_PLANES_LEN + e, c4::plane_bit(m, v, e));
@@ -451,10 +481,16 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
 
   const uint32_t gs = g < p.n_slots ? g : 0;
   Slot* st = p.slots + gs;
-  // evaluator outputs of this game: issued first so they travel with the slot header
+  // The game's state: ONE 128-byte line, 16 bytes per lane in one instruction; the evaluator's
+  // outputs for this game travel in the same round trip.
+  const uint4 hot = reinterpret_cast<const uint4*>(st)[sub];
   const float nn_logit = p.logprobs[(size_t)gs * 7 + (sub < 7 ? sub : 6)];
   const float nn_q = p.q[(size_t)gs * 2 + (sub & 1)];
-  bool active = (g < p.n_slots) && (st->status == kActive);
+  // header words to every lane of the group (lane 3: state, arena, root ref, rng word)
+  const uint32_t state0 = shfl_u32(hot.x, gbase + 3);
+  bool active = (g < p.n_slots) && (slot_status(state0) == kActive);
+  uint4 line = hot;          // what goes back to the slot at the end
+  bool store_line = false;
   // move RNG precompute (see the end of the kernel): what this game will need at its next move
   bool pre_need = false;
   uint32_t pre_n_moves = 0;
@@ -463,25 +499,25 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
   if (active) {
     Block* blocks = p.blocks + (size_t)g * p.blocks_per_slot;
 
-    uint64_t leaf_mask = st->leaf_mask, leaf_value = st->leaf_value;
-    uint64_t rmask = st->root_mask, rvalue = st->root_value;
-    uint32_t depth = st->depth;
-    uint32_t term = depth >> 8;          // terminal_state of the waiting leaf, computed when it was selected
-    depth &= 0xFFu;
-    uint32_t n_blocks = st->n_blocks;
-    uint32_t root_ref = st->root_ref;
-    uint32_t root_block = st->root_block;
-    uint32_t n_moves = st->n_moves;
-    uint32_t leaf_ref = st->leaf_ref;
-    const uint32_t rng_word = st->rng_word, rng_for = st->rng_for;
-    uint32_t ordinal = st->ordinal;
-    unsigned long long game_id = st->game_id;
+#define C4_BCAST64(lo, hi, src) (((uint64_t)shfl_u32(hi, gbase + (src)) << 32) | shfl_u32(lo, gbase + (src)))
+    uint64_t rmask = C4_BCAST64(hot.x, hot.y, 0), rvalue = C4_BCAST64(hot.z, hot.w, 0);
+    uint64_t leaf_mask = C4_BCAST64(hot.x, hot.y, 1), leaf_value = C4_BCAST64(hot.z, hot.w, 1);
+    unsigned long long game_id = C4_BCAST64(hot.x, hot.y, 2);
+#undef C4_BCAST64
+    uint32_t ordinal = shfl_u32(hot.z, gbase + 2);
+    const uint32_t arena0 = shfl_u32(hot.y, gbase + 3);
+    uint32_t root_ref = shfl_u32(hot.z, gbase + 3);
+    uint32_t rng_word = shfl_u32(hot.w, gbase + 3);
+    uint32_t depth = (state0 >> 8) & 0xFFu;
+    uint32_t n_moves = (state0 >> 16) & 0xFFu;
+    uint32_t term = (state0 >> 24) & 3u;          // terminal_state of the waiting leaf, computed when it was selected
+    uint32_t rng_for = state0 >> 26;
+    uint32_t n_blocks = arena0 & 0xFFFFu;
+    uint32_t root_block = arena0 >> 16;
+    // the recorded path as the line keeps it: lane 4 + j holds levels j, j + 4, j + 8, j + 12
+    uint4 pv = hot;
+    uint32_t leaf_ref = path_level(pv, st, depth, gbase);   // the waiting leaf's own entry
     bool fresh = false;                  // the slot took a new game in this launch
-    // path entries of this lane's backup levels (sub, sub+8): addresses do not depend on `depth`,
-    // so these loads go out together with the header
-    uint32_t path_a = st->path[sub];
-    uint32_t path_b = st->path[sub + 8];
-    uint32_t path_c = st->path[sub + 16];
     uint32_t err = 0;
     uint32_t root_n = 0;
     // One simulation per game per launch, plus a second one when the leaf just selected is terminal:
@@ -496,7 +532,7 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
     float cur_logit = nn_logit;
     float cur_qp = shfl_f32(nn_q, gbase), cur_qn = shfl_f32(nn_q, gbase + 1);
 
-    C4_STAMP(1, depth + n_blocks + leaf_ref + path_a + path_b + (uint32_t)leaf_mask);
+    C4_STAMP(1, depth + n_blocks + pv.x + (uint32_t)leaf_mask);
 #define C4_STAMP_TRIP1(i, force) do { if (sim == 0) C4_STAMP(i, force); } while (0)
 #pragma clang loop unroll(disable)
     for (uint32_t sim = 0; sim < max_sims; sim++) {
@@ -552,19 +588,22 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
       C4_STAMP_TRIP1(2, n_blocks);
       // ---------------- backpropagate_value: leaf -> root along the recorded path ----------
       root_n = 0;
-      for (uint32_t d = sub; d <= depth; d += 8) {
-        const uint32_t ref = (d < 8) ? path_a : (d < 16 ? path_b : (d < 24 ? path_c : st->path[d]));
-        Entry* e = &blocks[ref >> 3].e[ref & 7];
-        const bool odd = ((depth - d) & 1u) != 0;                             // value negated per step up
-        const uint32_t n1 = e->n + 1;
-        const float q1 = e->q_pen + (odd ? -v_pen : v_pen);
-        const float q2 = e->q_nopen + (odd ? -v_nopen : v_nopen);
-        e->n = n1;
-        e->q_pen = q1;
-        e->q_nopen = q2;
-        if (d == 0) root_n = n1;
+      if (sub >= 4) {   // level d on lane 4 + (d & 3): the first four levels update in parallel
+        for (uint32_t d = sub - 4; d <= depth; d += 4) {
+          const uint32_t c = d >> 2;
+          const uint32_t ref = c == 0 ? pv.x : (c == 1 ? pv.y : (c == 2 ? pv.z : (c == 3 ? pv.w : st->path_deep[d - kHotPath])));
+          Entry* e = &blocks[ref >> 3].e[ref & 7];
+          const bool odd = ((depth - d) & 1u) != 0;                             // value negated per step up
+          const uint32_t n1 = e->n + 1;
+          const float q1 = e->q_pen + (odd ? -v_pen : v_pen);
+          const float q2 = e->q_nopen + (odd ? -v_nopen : v_nopen);
+          e->n = n1;
+          e->q_pen = q1;
+          e->q_nopen = q2;
+          if (d == 0) root_n = n1;
+        }
       }
-      root_n = shfl_u32(root_n, gbase);
+      root_n = shfl_u32(root_n, gbase + 4);
       c_sims += 1;
       c_K += depth + 1;
       // The stores above are read back below through other lanes of THIS wavefront.  A wavefront's
@@ -687,14 +726,14 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
           fresh = true;
         } else {
           active = false;
-          if (sub == 0) { st->status = kIdle; st->ordinal = 0xFFFFFFFFu; }
+          if (sub == 0) { st->state = kIdle; st->ordinal = 0xFFFFFFFFu; }
           break;
         }
       }
       C4_STAMP_TRIP1(5, root_n);
       // ---------------- select_new_leaf (mcts.rs:160-183) -------------------------------
       err = select_leaf(p, blocks, st, rmask, rvalue, root_block, root_ref, root_n, p.c_exploration, sub, gbase,
-                        leaf_mask, leaf_value, depth, leaf_ref, path_a, path_b, path_c, c_S);
+                        leaf_mask, leaf_value, depth, leaf_ref, pv, c_S);
       if (err) break;
       C4_STAMP_TRIP1(6, depth);
       if (sim == 1) C4_STAMP_ANY(13);
@@ -711,7 +750,7 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
           c_hits += again ? 1 : 0;
         }
         if (again) {
-          if (depth >= 24) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // levels >= 24 are re-read from the slot's path
+          if (depth >= kHotPath) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // deeper levels are re-read from the slot's second line
           continue;
         }
       }
@@ -722,23 +761,19 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
     if (err) {
       if (sub == 0) raise_error(p, st, g, err);
     } else if (active) {
-      if (sub == 0) {
-        st->root_mask = rmask; st->root_value = rvalue;
-        st->leaf_mask = leaf_mask; st->leaf_value = leaf_value;
-        st->root_ref = root_ref; st->root_block = root_block; st->root_n = root_n;
-        st->depth = depth | (term << 8); st->n_blocks = n_blocks; st->n_moves = n_moves;
-        st->leaf_ref = leaf_ref;
-        publish_leaf_model(p, g, ordinal, leaf_mask);
-      }
-      // the recorded path goes back to the slot: lane `sub` holds levels sub, sub + 8, sub + 16
-      st->path[sub] = path_a;
-      if (depth >= 8) st->path[sub + 8] = path_b;
-      if (depth >= 16) st->path[sub + 16] = path_c;
+      if (sub == 0) publish_leaf_model(p, g, ordinal, leaf_mask);
       pre_need = fresh || (rng_for != n_moves + 1);   // after a move / refill the stored word is stale
       pre_n_moves = n_moves;
       pre_game_id = game_id;
       // ---------------- leaf -> evaluator input (c4r.rs:378-392) ----------------------
       encode_leaf<PlaneT>(p.planes, g, leaf_mask, leaf_value, sub);
+      // ---------------- the game's state goes back as one line: lane k owns dwords 4k..4k+3 ----
+      line = pv;                                                    // lanes 4..7: the recorded path
+      if (sub == 0) line = make_uint4((uint32_t)rmask, (uint32_t)(rmask >> 32), (uint32_t)rvalue, (uint32_t)(rvalue >> 32));
+      if (sub == 1) line = make_uint4((uint32_t)leaf_mask, (uint32_t)(leaf_mask >> 32), (uint32_t)leaf_value, (uint32_t)(leaf_value >> 32));
+      if (sub == 2) line = make_uint4((uint32_t)game_id, (uint32_t)(game_id >> 32), ordinal, root_n);
+      if (sub == 3) line = make_uint4(slot_state(kActive, depth, n_moves, term, fresh ? 0u : rng_for), n_blocks | (root_block << 16), root_ref, rng_word);
+      store_line = true;
     }
   }
 
@@ -765,8 +800,9 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
   // is computed here, in a step where no game of this wavefront moved, and kept in the slot.
   if (__ballot(c_moves != 0) == 0ull && pre_need) {
     const uint32_t w = c4::rng_first_u32_group(pre_game_id * (uint64_t)(42 + pre_n_moves), sub, gbase);
-    if (sub == 0) { st->rng_word = w; st->rng_for = pre_n_moves + 1; }
+    if (sub == 3) { line.w = w; line.x = (line.x & 0x03FFFFFFu) | ((pre_n_moves + 1u) << 26); }
   }
+  if (store_line) reinterpret_cast<uint4*>(st)[sub] = line;
   C4_STAMP(8, 0);
   if (lane == 0 && p.seq) {
     unsigned long long* my = p.stamps + ((size_t)(p.seq & 1) * p.n_waves + blockIdx.x) * 2;
@@ -879,14 +915,14 @@ __global__ __launch_bounds__(1024) void k_compact_plan(const Slot* slots, uint32
   if (threadIdx.x == 0) { s_active = 0; s_holes = 0; s_movers = 0; }
   __syncthreads();
   uint32_t mine = 0;
-  for (uint32_t g = threadIdx.x; g < n_slots; g += blockDim.x) mine += slots[g].status == kActive ? 1u : 0u;
+  for (uint32_t g = threadIdx.x; g < n_slots; g += blockDim.x) mine += slot_status(slots[g].state) == kActive ? 1u : 0u;
   atomicAdd(&s_active, mine);
   __syncthreads();
   const uint32_t A = s_active;
   // any bijection between holes (< A, idle) and movers (>= A, active) will do: which slot plays a
   // game changes nothing a game records
   for (uint32_t g = threadIdx.x; g < n_slots; g += blockDim.x) {
-    const bool act = slots[g].status == kActive;
+    const bool act = slot_status(slots[g].state) == kActive;
     if (g < A && !act) pairs[atomicAdd(&s_holes, 1u)].y = g;
     if (g >= A && act) pairs[atomicAdd(&s_movers, 1u)].x = g;
   }
@@ -900,7 +936,7 @@ __global__ __launch_bounds__(256) void k_compact_move(Params p, const CompactPla
   if (k >= plan->n_pairs) return;
   const uint32_t src = pairs[k].x, dst = pairs[k].y;
   const Slot* ss = p.slots + src;
-  const uint32_t n_blocks = ss->n_blocks;
+  const uint32_t n_blocks = ss->arena & 0xFFFFu;
   const uint4* sb = reinterpret_cast<const uint4*>(p.blocks + (size_t)src * p.blocks_per_slot);
   uint4* db = reinterpret_cast<uint4*>(p.blocks + (size_t)dst * p.blocks_per_slot);
   for (uint32_t i = threadIdx.x; i < n_blocks * 8u; i += blockDim.x) db[i] = sb[i];
@@ -908,7 +944,7 @@ __global__ __launch_bounds__(256) void k_compact_move(Params p, const CompactPla
   for (uint32_t e = threadIdx.x; e < C4_PLANES_LEN; e += blockDim.x) pl[(size_t)dst * C4_PLANES_LEN + e] = pl[(size_t)src * C4_PLANES_LEN + e];
   if (threadIdx.x < 16) reinterpret_cast<uint4*>(p.slots + dst)[threadIdx.x] = reinterpret_cast<const uint4*>(ss)[threadIdx.x];
   __syncthreads();
-  if (threadIdx.x == 0) { p.slots[src].status = kIdle; p.slots[src].ordinal = 0xFFFFFFFFu; }
+  if (threadIdx.x == 0) { p.slots[src].state = kIdle; p.slots[src].ordinal = 0xFFFFFFFFu; }
 }
 
 // Exclusive prefix sum of the per-game sample counts = where each game's records start in the packed
@@ -949,7 +985,7 @@ __global__ void k_leaf_keys(const Slot* slots, uint32_t n_slots, long long* keys
   if (g >= n_slots) return;
   const Slot* st = slots + g;
   long long key = -1;
-  if (st->status == kActive) {
+  if (slot_status(st->state) == kActive) {
     const uint64_t m = st->leaf_mask, v = st->leaf_value;
     uint64_t heights = 0;
     for (uint32_t c = 0; c < 7; c++) heights |= (uint64_t)__popcll(m & (c4::kCol0 << c)) << (3 * c);
@@ -1098,6 +1134,14 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
   if (cfg->n_slots == 0) return fail(C4_ERR_BAD_ARG, "n_slots must be > 0");
   if (cfg->planes_dtype > 1) return fail(C4_ERR_BAD_ARG, "planes_dtype must be 0 (f32) or 1 (bf16)");
   if (cfg->blocks_per_slot > kMaxBlocksPerSlot) return fail(C4_ERR_BAD_ARG, "blocks_per_slot is limited to 65535 (16-bit child links)");
+  // A game's arena is never reclaimed while it is played: it needs about 0.9 blocks per simulation,
+  // i.e. up to ~40 x n_mcts_iterations for the longest games.  Beyond 1523 iterations the worst case
+  // (43 n + 8) no longer fits 16-bit links and the arena is capped at 65535 blocks, which still
+  // covers every game up to about 2000 iterations; past that a long game would overflow its arena
+  // (C4_ERR_ARENA_OVERFLOW) in the middle of a job, so it is refused here, with the reason.
+  if (cfg->blocks_per_slot == 0 && cfg->n_mcts_iterations > 2048)
+    return fail(C4_ERR_BAD_ARG, "n_mcts_iterations > 2048 is not supported: a game's tree arena is limited to 65535 blocks "
+                                "(16-bit child links, ~0.9 blocks per simulation, never reclaimed during a game)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(C4_ERR_NO_DEVICE, "no HIP device visible");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(C4_ERR_BAD_ARG, "device ordinal out of range");
@@ -1243,7 +1287,10 @@ int c4_session_step(c4_session* s) {
   // the Dirichlet-noise and evaluation-cache extensions are separate instantiations: the default
   // kernel carries none of their registers or scratch
   const bool noise = s->p.dir_eps > 0.0f, cache = s->p.cache != nullptr;
-  auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(s->n_waves), dim3(64), 0, s->stream, s->p); };
+  // C4_STEP_LDS_BYTES (diagnostic, tools/occupancy_probe.sh): unused dynamic LDS per workgroup caps the
+  // wavefronts a CU holds (160 KB / bytes) without touching the code: how the launch time scales with occupancy
+  static const unsigned lds_pad = [] { const char* e = getenv("C4_STEP_LDS_BYTES"); return e ? (unsigned)atoi(e) : 0u; }();
+  auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(s->n_waves), dim3(64), lds_pad, s->stream, s->p); };
   if (s->cfg.planes_dtype == 0) {
     if (noise) { if (cache) launch(c4_step_kernel<float, true, true>); else launch(c4_step_kernel<float, true, false>); }
     else       { if (cache) launch(c4_step_kernel<float, false, true>); else launch(c4_step_kernel<float, false, false>); }
@@ -1462,9 +1509,10 @@ int c4_session_root_stats(c4_session* s, uint32_t slot, float policy[7], float* 
   if (policy) {
     // mcts.rs:396-412
     float cnt[7] = {0, 0, 0, 0, 0, 0, 0}, sum = 0.0f;
-    if (st.root_block) {
+    const uint32_t root_block = st.arena >> 16;
+    if (root_block) {
       Block cb;
-      HIP_TRY(hipMemcpy(&cb, s->p.blocks + base + st.root_block, sizeof cb, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(&cb, s->p.blocks + base + root_block, sizeof cb, hipMemcpyDeviceToHost));
       for (int c = 0; c < 7; c++) cnt[c] = (float)cb.e[c].n;
     }
     for (int c = 0; c < 7; c++) sum = sum + cnt[c];
@@ -1491,7 +1539,7 @@ int c4_session_leaves(c4_session* s, uint64_t* masks_host, uint64_t* values_host
   for (uint32_t g = 0; g < s->cfg.n_slots; g++) {
     if (masks_host) masks_host[g] = h[g].leaf_mask;
     if (values_host) values_host[g] = h[g].leaf_value;
-    if (status_host) status_host[g] = h[g].status;
+    if (status_host) status_host[g] = h[g].state & 0xFFu;
     if (ordinals_host) ordinals_host[g] = h[g].ordinal;
   }
   return C4_OK;

@@ -299,3 +299,35 @@ def test_play_games_narrows_the_tail_without_changing_samples():
             assert np.array_equal(x, y)
     assert st_wide["sims"] == st_small["sims"] == st_two["sims"]
     assert st_wide["rows_at_end"] < 1024 and st_small["rows_at_end"] == 128
+
+
+def test_search_width_beyond_the_arena_limit_is_refused_with_a_reason():
+    """n_mcts_iterations > 2048 cannot be guaranteed a large enough arena (16-bit child
+    links): the session refuses it at creation instead of failing in the middle of a job."""
+    from c4a0_amd._lib import C4Error
+    from c4a0_amd.session import DeviceSession
+
+    with pytest.raises(C4Error, match="n_mcts_iterations > 2048"):
+        DeviceSession(2, 3000, 6.6, 0.01)
+    s = DeviceSession(2, 2000, 6.6, 0.01)     # capped arena, still accepted
+    s.close()
+
+
+def test_second_device_after_the_first():
+    """sessions, the conv tower's LDS opt-in and the head kernel on device 1 after device 0
+    in the same process; the caller's current device is left alone.  Needs two visible devices."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device")
+    import c4a0_amd
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    reqs = [c4a0_amd.GameMetadata(40 + i, 0, 0) for i in range(12)]
+    out = []
+    for d in (0, 1):
+        dev = torch.device("cuda", d)
+        torch.manual_seed(3)
+        net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 2, 2)), dev, dtype=torch.bfloat16)
+        before = torch.cuda.current_device()
+        out.append(c4a0_amd.play_games(reqs, 64, 8, 6.6, 0.01, evaluator=net, device=dev, resident_games=8).to_records())
+        assert torch.cuda.current_device() == before
+    assert out[0][0].tobytes() == out[1][0].tobytes()

@@ -70,6 +70,32 @@ __global__ __launch_bounds__(64) void k_chase(const uint4* __restrict__ table, u
   if (acc == 0xdeadbeef) sink[0] = acc;
 }
 
+// the backup's pattern: every LANE updates one 16-byte entry of its own random line (read 12 bytes,
+// add, write back): 64 lines per wavefront instruction, a partial-line write each
+__global__ __launch_bounds__(64) void k_rmw16(uint4* table, uint32_t n_lines, uint32_t iters, uint32_t seed) {
+  const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  uint32_t h = mix(t * 0x9E3779B9u + seed);
+  for (uint32_t it = 0; it < iters; it++) {
+    h = mix(h + 0x68bc21ebu);
+    const uint32_t line = (uint32_t)(((uint64_t)h * n_lines) >> 32);
+    uint4* e = table + (size_t)line * 8 + (h & 7u) % 7u;
+    uint4 v = *e;
+    v.y += 1; v.z += it; v.w ^= h;       // x (the chain index of the other tests) stays
+    *e = v;
+  }
+}
+
+// the expand's pattern: a lane group writes one whole random 128-byte line
+__global__ __launch_bounds__(64) void k_write128(uint4* table, uint32_t n_lines, uint32_t iters, uint32_t seed) {
+  const uint32_t lane = threadIdx.x, sub = lane & 7, grp = (blockIdx.x * 64 + lane) >> 3;
+  uint32_t h = mix(grp * 0x9E3779B9u + seed);
+  for (uint32_t it = 0; it < iters; it++) {
+    h = mix(h + 0x68bc21ebu);
+    const uint32_t line = (uint32_t)(((uint64_t)h * n_lines) >> 32);
+    table[(size_t)line * 8 + sub] = make_uint4(line, it, sub, h);
+  }
+}
+
 static float time_ms(hipEvent_t a, hipEvent_t b) {
   float ms = 0;
   CHECK(hipEventElapsedTime(&ms, a, b));
@@ -121,6 +147,28 @@ int main(int argc, char** argv) {
       const double ms = time_ms(e0, e1);
       printf("{\"test\": \"chase\", \"table_MB\": %zu, \"wavefronts\": %d, \"depth\": %u, \"ms\": %.4f, \"ns_per_level\": %.1f, \"TBps\": %.3f}\n",
              mb, waves, depth, ms, ms * 1e6 / depth, (double)waves * 8 * depth * 128 / ms / 1e9);
+    }
+    // writes last (they destroy the chains): 16-byte read-modify-writes and whole-line writes
+    for (int wps : {1, 4, 8}) {
+      const uint32_t grid = 1024u * wps, iters = 500;
+      k_rmw16<<<grid, 64>>>(table, n_lines, iters, 1);
+      CHECK(hipEventRecord(e0));
+      k_rmw16<<<grid, 64>>>(table, n_lines, iters, 2);
+      CHECK(hipEventRecord(e1));
+      CHECK(hipDeviceSynchronize());
+      double ms = time_ms(e0, e1);
+      double ops = (double)grid * 64 * iters;
+      printf("{\"test\": \"rmw16\", \"table_MB\": %zu, \"waves_per_simd\": %d, \"ms\": %.4f, \"G_updates_per_s\": %.3f, \"algorithmic_TBps\": %.3f}\n",
+             mb, wps, ms, ops / ms / 1e6, ops * 32 / ms / 1e9);
+      k_write128<<<grid, 64>>>(table, n_lines, iters, 3);
+      CHECK(hipEventRecord(e0));
+      k_write128<<<grid, 64>>>(table, n_lines, iters, 4);
+      CHECK(hipEventRecord(e1));
+      CHECK(hipDeviceSynchronize());
+      ms = time_ms(e0, e1);
+      ops = (double)grid * 8 * iters;
+      printf("{\"test\": \"write128\", \"table_MB\": %zu, \"waves_per_simd\": %d, \"ms\": %.4f, \"G_lines_per_s\": %.3f, \"TBps\": %.3f}\n",
+             mb, wps, ms, ops / ms / 1e6, ops * 128 / ms / 1e9);
     }
     CHECK(hipFree(table));
     fflush(stdout);
