@@ -156,6 +156,10 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    if os.environ.get("C4_BENCH_WATCHDOG"):   # debugging aid: dump every thread's Python stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["C4_BENCH_WATCHDOG"]), exit=True, file=sys.stderr)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20,
@@ -182,6 +186,9 @@ def main():
     ap.add_argument("--sessions", type=int, default=2,
                     help="the resident games are split over this many sessions that replay their HIP graphs "
                          "concurrently on separate streams (1 = one session, one stream)")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="internal: compute the cpu_baseline object alone and print it (the bench runs this leg in a child "
+                         "process under a time limit, so that the checker can never cost the GPU line)")
     ap.add_argument("--whole-job", action="store_true",
                     help="instead of the steady-state bench: the reference's default self-play job, whole, in callback and device modes (own JSON line)")
     ap.add_argument("--whole-job-games", type=int, default=1700)
@@ -197,10 +204,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # C4_BENCH_SAME_DEVICE=1 (test knob, with C4_BENCH_BACKEND=gloo): every rank on device 0, so the whole
+    # N > 1 code path can be exercised on a one-GPU box
+    dev_index = 0 if os.environ.get("C4_BENCH_SAME_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if args.whole_job:
         return whole_job(args, device, real_stdout)
+    if args.cpu_baseline_only:
+        from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+        torch.manual_seed(1337)
+        net = InferenceNet(ConnectFourNet(ModelConfig(args.blocks, args.channels, 4, 2)), device, dtype=torch.bfloat16)
+        out = cpu_baseline(net, device, args.n_mcts, min(usable_cores(), 64), args.cpu_baseline_seconds)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        return
     from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig, flops_per_leaf
     from c4a0_amd.session import DeviceSession
 
@@ -251,7 +268,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")   # only reached without a launcher (the world-size-1 knob above)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("C4_BENCH_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; "gloo" only for the one-GPU test
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = device if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")   # where small reductions live
 
     def counters():
         tot = {}
@@ -340,7 +362,7 @@ def main():
             want_ids = torch.repeat_interleave(torch.arange(n_games * world, device=merged.device), cnt)
             got_ids = merged[:, :8].contiguous().view(torch.int64).reshape(-1)
             n_fin = int((cnt > 0).sum().item())
-            done_all = torch.tensor([float(sum(sp.counters()["games_done"] for sp in sessions))], dtype=torch.float64, device=device)
+            done_all = torch.tensor([float(sum(sp.counters()["games_done"] for sp in sessions))], dtype=torch.float64, device=red_dev)
             dist.all_reduce(done_all, op=dist.ReduceOp.SUM)
             ok = bool(torch.equal(got_ids, want_ids)) and merged.shape[0] == int(cnt.sum().item()) and n_fin == int(done_all.item())
             allgather = {"ms": (tg1 - tg0) * 1e3, "records_per_rank": [int(p_.shape[0]) for p_ in per_rank],
@@ -351,9 +373,9 @@ def main():
 
     games, sims, elapsed_max = float(d["games_done"]), float(d["sims"]), elapsed
     if dist is not None:
-        t = torch.tensor([games, sims, float(d["ref_skipped_sims"])], dtype=torch.float64, device=device)
+        t = torch.tensor([games, sims, float(d["ref_skipped_sims"])], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        m = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        m = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         games, sims, skipped = t.tolist()
         elapsed_max = float(m.item())
@@ -413,6 +435,8 @@ def main():
                          "avg_launch_us": avg_kernel_s * 1e6,
                          "device_clock": {"avg_kernel_us": dev_s * 1e6, "achieved": achieved_dev, "frac": achieved_dev / HBM_PEAK_GBPS,
                                           "note": "in-kernel s_memrealtime stamps; the HIP-event bracket adds the dispatch and completion latency of one launch"},
+                         "practical_ceilings": {"random_128B_lines_from_HBM_GBps": 6700, "dependent_line_chain_ns_per_level_idle": 550,
+                                                "source": "profiles/r02_gather_lab.jsonl (tools/gather_lab.hip on MI355X): what the memory system gives the tree walk's access pattern; at this launch size the kernel is bound by one wavefront's dependent chain, not by bytes (DESIGN.md 4.2)"},
                          "launches_measured": n_inst, "games_per_launch": sess.n_slots,
                          "algorithmic_bytes_per_launch": ab["total"] / n_inst,
                          "bytes_per_sim": {k: v / max(1, di["sims"]) for k, v in ab.items()},
@@ -426,8 +450,21 @@ def main():
         if allgather is not None:
             out["sample_allgather"] = allgather
         if world == 1 and not args.no_cpu_baseline:
+            # the checker's leg runs in a child process under a time limit: whatever happens to it, the GPU line is printed
+            import subprocess
+            for sp in sessions:
+                sp.close()
+            sessions = []
+            torch.cuda.empty_cache()
             try:
-                out["cpu_baseline"] = cpu_baseline(net, device, n_iter, min(usable_cores(), 64), args.cpu_baseline_seconds)
+                limit = max(120.0, 8.0 * args.cpu_baseline_seconds)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--n-mcts", str(n_iter), "--blocks", str(args.blocks),
+                                    "--channels", str(args.channels), "--cpu-baseline-seconds", str(args.cpu_baseline_seconds)],
+                                   capture_output=True, text=True, timeout=limit, cwd=ROOT)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not line:
+                    raise RuntimeError(f"child exited with {r.returncode}: {r.stderr[-300:]}")
+                out["cpu_baseline"] = json.loads(line[-1])
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -460,9 +460,11 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
 #ifdef C4_PHASE_STAMPS
   if (lane == 0) for (int i = 9; i < 16; i++) p.phase[(size_t)blockIdx.x * 16 + i] = 0;
 #endif
-  if (blockIdx.x == 0 && p.seq > 1) {
-    // duration of the PREVIOUS launch = last wavefront end - first wavefront start (its stamps are
-    // complete: kernel boundary); one writer, no atomics
+  if (blockIdx.x == p.n_waves) {
+    // The extra workgroup a timed launch carries (it owns no games): duration of the PREVIOUS launch =
+    // last wavefront end - first wavefront start (its stamps are complete: kernel boundary); one
+    // writer, no atomics, and no game's critical path carries the reduction.
+    if (p.seq <= 1) return;
     const unsigned long long* prev = p.stamps + (size_t)((p.seq - 1) & 1) * p.n_waves * 2;
     unsigned long long lo = ~0ull, hi = 0ull;
     for (uint32_t w = lane; w < p.n_waves; w += 64) {
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
       hi = oh > hi ? oh : hi;
     }
     if (lane == 0 && hi > lo) { p.clock_acc[0] += hi - lo; p.clock_acc[1] += 1; }
+    return;
   }
 
   const uint32_t gs = g < p.n_slots ? g : 0;
@@ -1106,7 +1109,7 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
       (e = hipMalloc(&p.glob, sizeof(Globals))) != hipSuccess ||
       (e = hipMalloc(&p.stamps, (size_t)s->n_waves * 4 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.clock_acc, 2 * sizeof(unsigned long long))) != hipSuccess ||
-      (e = hipMalloc(&p.phase, (size_t)s->n_waves * 16 * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMalloc(&p.phase, ((size_t)s->n_waves + 1) * 16 * sizeof(unsigned long long))) != hipSuccess ||   // + the timing helper workgroup (diagnostic builds stamp it too)
       (e = hipMalloc(&s->ln_tab_dev, (size_t)n_ln * sizeof(float))) != hipSuccess ||
       (e = hipHostMalloc(&s->probe_host, sizeof(Globals))) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s->probe_event, hipEventDisableTiming)) != hipSuccess)
@@ -1120,7 +1123,7 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(p.stamps, 0, (size_t)s->n_waves * 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(p.clock_acc, 0, 2 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(p.phase, 0, (size_t)s->n_waves * 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(p.phase, 0, ((size_t)s->n_waves + 1) * 16 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(p.slots, 0, n * sizeof(Slot)));
   HIP_TRY(hipMemset(p.glob, 0, sizeof(Globals)));
   HIP_TRY(hipMemset(p.wave_ctr, 0, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long)));
@@ -1290,7 +1293,8 @@ int c4_session_step(c4_session* s) {
   // C4_STEP_LDS_BYTES (diagnostic, tools/occupancy_probe.sh): unused dynamic LDS per workgroup caps the
   // wavefronts a CU holds (160 KB / bytes) without touching the code: how the launch time scales with occupancy
   static const unsigned lds_pad = [] { const char* e = getenv("C4_STEP_LDS_BYTES"); return e ? (unsigned)atoi(e) : 0u; }();
-  auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(s->n_waves), dim3(64), lds_pad, s->stream, s->p); };
+  // a timed launch (seq != 0) carries one extra workgroup that folds the previous launch's stamps
+  auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(s->n_waves + (s->p.seq ? 1u : 0u)), dim3(64), lds_pad, s->stream, s->p); };
   if (s->cfg.planes_dtype == 0) {
     if (noise) { if (cache) launch(c4_step_kernel<float, true, true>); else launch(c4_step_kernel<float, true, false>); }
     else       { if (cache) launch(c4_step_kernel<float, false, true>); else launch(c4_step_kernel<float, false, false>); }

@@ -222,13 +222,20 @@ class DeviceSession:
         if q_out.data_ptr() != q.data_ptr():
             q.copy_(q_out.reshape(r, 2))
 
+    NARROW_CHECK_ROUNDS = 64   # lock-step rounds between two looks at the tail (a stream synchronisation each)
+
     def narrow_if_worthwhile(self, multiple: int = 256) -> bool:
         """Tail of a job: when every request has been started and at most half of the rows still hold
         a game, compact() the session.  True if `self.rows` changed (captured graphs are then stale).
-        Synchronises only when it acts."""
+
+        The decision is taken from a SYNCHRONOUS read of the session's counters, and callers ask at
+        fixed round counts (NARROW_CHECK_ROUNDS), so the step at which a session narrows is a function of
+        the games alone, not of host or GPU timing: the evaluator's batch shape at every step -- on which
+        a library GEMM's low bits can depend -- is reproducible run to run."""
         if getattr(self, "leaf_models", None) is not None or self.rows <= multiple:
             return False
-        done, started, _err = self.progress()
+        c = self.counters()                     # synchronises this session's stream
+        done, started = c["games_done"], c["games_started"]
         if started < self.n_games or (self.n_games - done) > self.rows // 2:
             return False
         before = self.rows
@@ -251,6 +258,7 @@ class DeviceSession:
         # `poll_every` eager steps) are outstanding at any time.
         max_chunks_in_flight = 2
         inflight = []
+        chunks = 0
         while True:
             if graph is not None:
                 graph.replay()
@@ -274,7 +282,8 @@ class DeviceSession:
                     self.raise_if_device_error()
                 if done >= self.n_games:
                     break
-                if graph is not None and self.narrow_if_worthwhile():
+                chunks += 1
+                if graph is not None and chunks % max(1, self.NARROW_CHECK_ROUNDS // steps_per_graph) == 0 and self.narrow_if_worthwhile():
                     inflight.clear()
                     graph = self.capture_steps(evaluator, steps_per_graph)   # the old graph carries the old width
             if max_steps is not None and steps >= max_steps:
@@ -312,6 +321,7 @@ def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator
         st.synchronize()
         graphs.append(s.capture_steps(evaluator, steps_per_graph, stream=st))
     steps = [0] * len(sessions)
+    chunks = [0] * len(sessions)
     live = [s.n_games > 0 for s in sessions]
     inflight: List[List[torch.cuda.Event]] = [[] for _ in sessions]
     while any(live):
@@ -330,9 +340,10 @@ def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator
             if err:
                 torch.cuda.synchronize(dev)
                 s.raise_if_device_error()
+            chunks[i] += 1
             if done >= s.n_games:
                 live[i] = False
-            elif s.narrow_if_worthwhile():   # tail: fewer rows to evaluate, see DeviceSession.compact
+            elif chunks[i] % max(1, s.NARROW_CHECK_ROUNDS // steps_per_graph) == 0 and s.narrow_if_worthwhile():   # tail: fewer rows to evaluate, see DeviceSession.compact
                 inflight[i].clear()
                 graphs[i] = s.capture_steps(evaluator, steps_per_graph, stream=st)
     torch.cuda.synchronize(dev)

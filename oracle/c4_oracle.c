@@ -1192,14 +1192,23 @@ typedef struct {
   uint64_t n_iter; float c_exploration, c_ply_penalty;
 } c4o_async;
 
+/* The rings hold every game at once, so a push can only find its cell "full" while the consumer
+ * that emptied it a lap ago has claimed it but not yet released it (preempted between its CAS and
+ * its sequence store): wait for it -- dropping the item would lose a game. */
+static void queue_push_wait(c4o_queue* q, const c4o_job* j) {
+  unsigned spins = 0;
+  while (!queue_push(q, j)) backoff(&spins);
+}
+
 static void async_push_nn(c4o_async* a, uint64_t gi) {
   c4o_job j;
+  memset(&j, 0, sizeof j);
   j.game = gi;
-  queue_push(&a->nn_queue, &j);
+  queue_push_wait(&a->nn_queue, &j);
 }
 
 static void async_push_jobs(c4o_async* a, const c4o_job* j, uint64_t n) {
-  for (uint64_t i = 0; i < n; i++) queue_push(&a->mcts_queue, &j[i]);
+  for (uint64_t i = 0; i < n; i++) queue_push_wait(&a->mcts_queue, &j[i]);
 }
 
 /* MctsThread::loop_until_close (self_play.rs:268-323) */

@@ -50,3 +50,26 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_result(tmp_path, mode, n_
     for g in single.results:
         mine = [(s.mask, s.value) for s in g.samples]
         assert mine == [(m, v) for m, v, *_ in ob[g.metadata.game_id]]
+
+
+def test_bench_multi_rank_path_on_one_gpu(tmp_path):
+    """bench.py's N > 1 code path (ids sharded rank + W i, barriers, max-over-ranks timing, the sample
+    exchange and its completeness check) with two ranks that share the one GPU: launched exactly as the
+    driver launches it, except for the backend (gloo: RCCL refuses two ranks on one device)."""
+    import json
+
+    env = dict(os.environ, C4_BENCH_SAME_DEVICE="1", C4_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--rounds-per-step", "128", "--preroll", "1600"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert "cpu_baseline" not in out                                  # rank 0 at N = 1 only
+    ag = out["sample_allgather"]
+    assert "error" not in ag, ag
+    assert ag["merged_in_request_order_and_complete"] is True and ag["games_merged"] > 0
+    assert len(ag["records_per_rank"]) == 2 and min(ag["records_per_rank"]) > 0

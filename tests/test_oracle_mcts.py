@@ -274,6 +274,12 @@ def test_async_topology_gives_the_samples_of_the_lockstep_restatement():
     assert flat(got) == {g: v for g, v in flat(want2).items() if g in (1, 4)}
     assert O.self_play([], 64, 9, 6.6, 0.01, "hash", n_threads=4, topology="async")[0] == {}
 
+    # regression (round 2): oversubscribed threads and tiny rings -- a producer that laps a preempted
+    # consumer must wait for its cell, not drop the game (the job used to hang now and then)
+    for _ in range(150):
+        got, gst = O.self_play(reqs[:5], 64, 9, 6.6, 0.01, "uniform", n_threads=16, topology="async")
+        assert gst["n_games"] == 5 and len(got) == 5
+
     def failing(_m, _x):
         raise RuntimeError("evaluator failure")
     with pytest.raises(RuntimeError):
