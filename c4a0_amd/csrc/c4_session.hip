@@ -93,12 +93,10 @@ C4_DEV constexpr uint32_t slot_state(uint32_t status, uint32_t depth, uint32_t n
   return status | (depth << 8) | (n_moves << 16) | (term << 24) | (rng_for << 26);
 }
 C4_DEV uint32_t slot_status(uint32_t state) { return state & 0xFFu; }
-C4_DEV uint32_t& slot_path_ref(Slot* st, uint32_t level) {   // where level `level` of the path lives
-  return level < kHotPath ? st->path[4 * (level & 3u) + (level >> 2)] : st->path_deep[level - kHotPath];
-}
 static_assert(sizeof(Block) == 128 && sizeof(Entry) == 16 && sizeof(Tail) == 16 && sizeof(c4_sample_rec) == 64, "layout");
 
 enum : uint32_t { kIdle = 0, kActive = 1 };
+constexpr uint32_t kWavesPerTimingHelper = 1024;   // stamps one timing helper workgroup reduces
 
 // Diagnostic build only (-DC4_PHASE_STAMPS, tools/phase_profile.py): per-wavefront device-clock
 // stamps at the phase boundaries of the step kernel.  `force` makes the stamp wait for the values
@@ -133,7 +131,7 @@ struct Params {
   Block* blocks;
   unsigned long long* wave_ctr;  // [n_waves][CTR_N]
   unsigned long long* stamps;    // [2][n_waves][2] start/end device clock of each wavefront, by launch parity
-  unsigned long long* clock_acc; // [2] sum of (last end - first start) over launches, number of launches summed
+  unsigned long long* clock_acc; // [0] sum of (last end - first start) over launches, [1] launches summed, [2..4] the timing helpers' scratch
   uint32_t n_waves;
   uint32_t seq;                  // launch sequence number
   unsigned long long* phase;     // diagnostic build: [n_waves][16] phase stamps of the last launch
@@ -268,6 +266,7 @@ C4_DEV uint32_t select_leaf(const Params& p, const Block* blocks, Slot* st, uint
   uint64_t m = rmask, v = rvalue;
   uint32_t blk = root_block, d = 0, last_ref = root_ref;
   float ln_np = ln_visits(p, root_n);                     // ln(parent visits) of the level being scored
+  uint32_t nan_seen = 0;
   pv.x = (sub == 4) ? root_ref : pv.x;                    // level 0 of the path = the root's own entry
   while (blk != 0 && d + 1 < kMaxPath) {
     const uint4 ce = load_block_lane(blocks, blk, sub);   // {n, q_pen, q_nopen, prior} | tail
@@ -276,21 +275,20 @@ C4_DEV uint32_t select_leaf(const Params& p, const Block* blocks, Slot* st, uint
     const float my_ln = ln_visits(p, sub < 7 ? ce.x : 0u);
     const uint32_t legal = c4::legal_mask(m);
     const bool ok = sub < 7 && ((legal >> sub) & 1u);
-    float score = 0.0f;
-    if (ok) {
-      // uct_value (mcts.rs:359-388); ln(1) == 0 makes every first-level score -0+0
-      const float nf = (float)ce.x + 1.0f;
-      const float qv = __uint_as_float(ce.y) / nf;
-      float ex = ln_np / nf;
-      ex = __builtin_sqrtf(ex);
-      ex = ex * (__uint_as_float(ce.w) + 1e-8f);
-      const float cx = c_exploration * ex;
-      score = -qv + cx;
-    }
-    // max_by_key keeps the LAST maximum (mcts.rs:165-173); NaN panics (utils.rs:12)
-    const bool isn = ok && (score != score);
-    const unsigned long long nan_ballot = __ballot(isn) >> gbase & 0xFFull;
-    if (nan_ballot && __popc(legal) >= 2) return C4_ERR_NAN_IN_TREE;
+    // uct_value (mcts.rs:359-388), computed on every lane without a branch (a lane without a legal
+    // move computes on whatever it loaded and its score is never looked at); ln(1) == 0 makes every
+    // first-level score -0+0
+    const float nf = (float)ce.x + 1.0f;
+    const float qv = __uint_as_float(ce.y) / nf;
+    float ex = ln_np / nf;
+    ex = __builtin_sqrtf(ex);
+    ex = ex * (__uint_as_float(ce.w) + 1e-8f);
+    const float cx = c_exploration * ex;
+    const float score = -qv + cx;
+    // max_by_key keeps the LAST maximum (mcts.rs:165-173); a NaN among two or more candidates panics
+    // (utils.rs:12).  The walk finishes the level either way and reports after the loop: an errored
+    // game's state is never used again.
+    nan_seen |= (ok && (score != score)) ? (uint32_t)(__popc(legal) >= 2) : 0u;
     // Argmax as the maximum of a 64-bit key: high word = the score mapped monotonically onto
     // unsigned integers (-0 first folded into +0: the two compare equal as floats), low word =
     // column + 1, so equal scores go to the LAST column and a lane without a legal move (key 0)
@@ -327,7 +325,7 @@ C4_DEV uint32_t select_leaf(const Params& p, const Block* blocks, Slot* st, uint
     levels += 1;
   }
   leaf_mask = m; leaf_value = v; depth = d; leaf_ref = last_ref;
-  return 0;
+  return ((__ballot(nan_seen != 0) >> gbase) & 0xFFull) ? (uint32_t)C4_ERR_NAN_IN_TREE : 0u;
 }
 
 C4_DEV void raise_error(const Params& p, Slot* st, uint32_t g, uint32_t code) {
@@ -439,12 +437,12 @@ __global__ __launch_bounds__(64) void c4_start_kernel(Params p) {
 //   -> gate / move / finish / refill (self_play.rs:283-308, mcts.rs:187-222, 271-313)
 //   -> select (mcts.rs:160-183)  ->  encode the new leaf (c4r.rs:378-392)
 // ------------------------------------------------------------------------------------------
-// Wavefronts per SIMD the default instantiation is compiled for.  Measured (tools/tree_roofline.py):
-// 4 (127 registers, no spill) and 3 run alike up to 65 536 games per launch and 4 is 8 % slower at
-// 131 072; 5 (96 registers, spills) is 20 % slower: the kernel is not occupancy-bound.  The
-// extension instantiations keep what they need.
+// Wavefronts per SIMD the default instantiation is compiled for.  Measured (tools/tree_roofline.py, 65 536 /
+// 131 072 games per launch): 3 (137 registers) 37.7 / 71.4 us, 4 (127 registers, no spill) 35.1 / 64.4 us,
+// 5 (96 registers, spills) 46.2 / 93.6 us; at 2 048 games all three take 10.3 us.  The extension
+// instantiations keep what they need.
 #ifndef C4_STEP_WAVES
-#define C4_STEP_WAVES 3
+#define C4_STEP_WAVES 4
 #endif
 template <typename PlaneT, bool NOISE, bool CACHE>
 __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_step_kernel(Params p) {
@@ -460,17 +458,21 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
 #ifdef C4_PHASE_STAMPS
   if (lane == 0) for (int i = 9; i < 16; i++) p.phase[(size_t)blockIdx.x * 16 + i] = 0;
 #endif
-  if (blockIdx.x == p.n_waves) {
-    // The extra workgroup a timed launch carries (it owns no games): duration of the PREVIOUS launch =
-    // last wavefront end - first wavefront start (its stamps are complete: kernel boundary); one
-    // writer, no atomics, and no game's critical path carries the reduction.
+  if (blockIdx.x >= p.n_waves) {
+    // The extra workgroups a timed launch carries (they own no games; one per 1 024 wavefronts):
+    // duration of the PREVIOUS launch = last wavefront end - first wavefront start (its stamps are
+    // complete: kernel boundary).  Each helper reduces its chunk, the last one to finish adds the
+    // launch to the totals.  No game's critical path carries any of this.
     if (p.seq <= 1) return;
+    const uint32_t h = blockIdx.x - p.n_waves, n_helpers = gridDim.x - p.n_waves;
     const unsigned long long* prev = p.stamps + (size_t)((p.seq - 1) & 1) * p.n_waves * 2;
+    const uint32_t w_end = (h + 1) * kWavesPerTimingHelper < p.n_waves ? (h + 1) * kWavesPerTimingHelper : p.n_waves;
     unsigned long long lo = ~0ull, hi = 0ull;
-    for (uint32_t w = lane; w < p.n_waves; w += 64) {
-      const unsigned long long a = prev[2 * w], b = prev[2 * w + 1];
-      lo = a < lo ? a : lo;
-      hi = b > hi ? b : hi;
+#pragma unroll 8
+    for (uint32_t w = h * kWavesPerTimingHelper + lane; w < w_end; w += 64) {
+      const ulonglong2 ab = reinterpret_cast<const ulonglong2*>(prev)[w];
+      lo = ab.x < lo ? ab.x : lo;
+      hi = ab.y > hi ? ab.y : hi;
     }
     for (int off = 1; off < 64; off <<= 1) {
       const unsigned long long ol = ((unsigned long long)shfl_u32((uint32_t)(lo >> 32), (int)(lane ^ off)) << 32) | shfl_u32((uint32_t)lo, (int)(lane ^ off));
@@ -478,7 +480,18 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
       lo = ol < lo ? ol : lo;
       hi = oh > hi ? oh : hi;
     }
-    if (lane == 0 && hi > lo) { p.clock_acc[0] += hi - lo; p.clock_acc[1] += 1; }
+    if (lane == 0) {
+      unsigned long long* tmp = p.clock_acc + 2;   // [2] running min start, [3] running max end, [4] helpers done
+      atomicMin(&tmp[0], lo);
+      atomicMax(&tmp[1], hi);
+      __threadfence();
+      if (atomicAdd(&tmp[2], 1ull) == n_helpers - 1) {
+        __threadfence();
+        const unsigned long long first = atomicExch(&tmp[0], ~0ull), last = atomicExch(&tmp[1], 0ull);
+        atomicExch(&tmp[2], 0ull);
+        if (last > first) { p.clock_acc[0] += last - first; p.clock_acc[1] += 1; }
+      }
+    }
     return;
   }
 
@@ -1082,6 +1095,11 @@ int c4_device_count(int* out) {
   return C4_OK;
 }
 
+static hipError_t reset_clock_acc(unsigned long long* acc_dev) {
+  const unsigned long long init[5] = {0ull, 0ull, ~0ull, 0ull, 0ull};   // totals; running min start, max end, helpers done
+  return hipMemcpy(acc_dev, init, sizeof init, hipMemcpyHostToDevice);
+}
+
 static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   uint64_t bps = cfg->blocks_per_slot;
   if (bps == 0) bps = 43ull * (cfg->n_mcts_iterations ? cfg->n_mcts_iterations : 1) + 8;
@@ -1108,8 +1126,8 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
       (e = hipMalloc(&p.wave_ctr, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.glob, sizeof(Globals))) != hipSuccess ||
       (e = hipMalloc(&p.stamps, (size_t)s->n_waves * 4 * sizeof(unsigned long long))) != hipSuccess ||
-      (e = hipMalloc(&p.clock_acc, 2 * sizeof(unsigned long long))) != hipSuccess ||
-      (e = hipMalloc(&p.phase, ((size_t)s->n_waves + 1) * 16 * sizeof(unsigned long long))) != hipSuccess ||   // + the timing helper workgroup (diagnostic builds stamp it too)
+      (e = hipMalloc(&p.clock_acc, 5 * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMalloc(&p.phase, ((size_t)s->n_waves + 64) * 16 * sizeof(unsigned long long))) != hipSuccess ||   // + the timing helper workgroups (diagnostic builds stamp them too)
       (e = hipMalloc(&s->ln_tab_dev, (size_t)n_ln * sizeof(float))) != hipSuccess ||
       (e = hipHostMalloc(&s->probe_host, sizeof(Globals))) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s->probe_event, hipEventDisableTiming)) != hipSuccess)
@@ -1122,8 +1140,8 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(p.stamps, 0, (size_t)s->n_waves * 4 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(p.clock_acc, 0, 2 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(p.phase, 0, ((size_t)s->n_waves + 1) * 16 * sizeof(unsigned long long)));
+  HIP_TRY(reset_clock_acc(p.clock_acc));
+  HIP_TRY(hipMemset(p.phase, 0, ((size_t)s->n_waves + 64) * 16 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(p.slots, 0, n * sizeof(Slot)));
   HIP_TRY(hipMemset(p.glob, 0, sizeof(Globals)));
   HIP_TRY(hipMemset(p.wave_ctr, 0, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long)));
@@ -1214,7 +1232,7 @@ int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n
   s->n_games = n_games;
   s->have_games = true;
   HIP_TRY(hipMemset(s->p.stamps, 0, (size_t)s->n_waves_cap * 4 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(s->p.clock_acc, 0, 2 * sizeof(unsigned long long)));
+  HIP_TRY(reset_clock_acc(s->p.clock_acc));
   // a new list of games may come with new evaluator weights: forget the old evaluations
   if (s->p.cache) HIP_TRY(hipMemset(s->p.cache, 0, ((size_t)s->p.cache_mask + 1) * 64));
   s->seq = 0;
@@ -1293,8 +1311,9 @@ int c4_session_step(c4_session* s) {
   // C4_STEP_LDS_BYTES (diagnostic, tools/occupancy_probe.sh): unused dynamic LDS per workgroup caps the
   // wavefronts a CU holds (160 KB / bytes) without touching the code: how the launch time scales with occupancy
   static const unsigned lds_pad = [] { const char* e = getenv("C4_STEP_LDS_BYTES"); return e ? (unsigned)atoi(e) : 0u; }();
-  // a timed launch (seq != 0) carries one extra workgroup that folds the previous launch's stamps
-  auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(s->n_waves + (s->p.seq ? 1u : 0u)), dim3(64), lds_pad, s->stream, s->p); };
+  // a timed launch (seq != 0) carries extra workgroups that fold the previous launch's stamps
+  const uint32_t helpers = s->p.seq ? (s->n_waves + kWavesPerTimingHelper - 1) / kWavesPerTimingHelper : 0u;
+  auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(s->n_waves + helpers), dim3(64), lds_pad, s->stream, s->p); };
   if (s->cfg.planes_dtype == 0) {
     if (noise) { if (cache) launch(c4_step_kernel<float, true, true>); else launch(c4_step_kernel<float, true, false>); }
     else       { if (cache) launch(c4_step_kernel<float, false, true>); else launch(c4_step_kernel<float, false, false>); }
