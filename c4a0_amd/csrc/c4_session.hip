@@ -437,6 +437,42 @@ __global__ __launch_bounds__(64) void c4_start_kernel(Params p) {
 //   -> gate / move / finish / refill (self_play.rs:283-308, mcts.rs:187-222, 271-313)
 //   -> select (mcts.rs:160-183)  ->  encode the new leaf (c4r.rs:378-392)
 // ------------------------------------------------------------------------------------------
+// The extra workgroups a timed launch carries (they own no games; one per kWavesPerTimingHelper
+// wavefronts): duration of the PREVIOUS launch = last wavefront end - first wavefront start (its stamps are
+// complete: kernel boundary).  Each helper reduces its chunk, the last one to finish adds the launch to the
+// totals.  No game's critical path carries any of this.
+C4_DEV void timing_helper(const Params& p, uint32_t lane) {
+  if (p.seq <= 1) return;
+  const uint32_t h = blockIdx.x - p.n_waves, n_helpers = gridDim.x - p.n_waves;
+  const unsigned long long* prev = p.stamps + (size_t)((p.seq - 1) & 1) * p.n_waves * 2;
+  const uint32_t w_end = (h + 1) * kWavesPerTimingHelper < p.n_waves ? (h + 1) * kWavesPerTimingHelper : p.n_waves;
+  unsigned long long lo = ~0ull, hi = 0ull;
+#pragma unroll 8
+  for (uint32_t w = h * kWavesPerTimingHelper + lane; w < w_end; w += 64) {
+    const ulonglong2 ab = reinterpret_cast<const ulonglong2*>(prev)[w];
+    lo = ab.x < lo ? ab.x : lo;
+    hi = ab.y > hi ? ab.y : hi;
+  }
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long ol = ((unsigned long long)shfl_u32((uint32_t)(lo >> 32), (int)(lane ^ off)) << 32) | shfl_u32((uint32_t)lo, (int)(lane ^ off));
+    const unsigned long long oh = ((unsigned long long)shfl_u32((uint32_t)(hi >> 32), (int)(lane ^ off)) << 32) | shfl_u32((uint32_t)hi, (int)(lane ^ off));
+    lo = ol < lo ? ol : lo;
+    hi = oh > hi ? oh : hi;
+  }
+  if (lane == 0) {
+    unsigned long long* tmp = p.clock_acc + 2;   // [2] running min start, [3] running max end, [4] helpers done
+    atomicMin(&tmp[0], lo);
+    atomicMax(&tmp[1], hi);
+    __threadfence();
+    if (atomicAdd(&tmp[2], 1ull) == n_helpers - 1) {
+      __threadfence();
+      const unsigned long long first = atomicExch(&tmp[0], ~0ull), last = atomicExch(&tmp[1], 0ull);
+      atomicExch(&tmp[2], 0ull);
+      if (last > first) { p.clock_acc[0] += last - first; p.clock_acc[1] += 1; }
+    }
+  }
+}
+
 // Wavefronts per SIMD the default instantiation is compiled for.  Measured (tools/tree_roofline.py, 65 536 /
 // 131 072 games per launch): 3 (137 registers) 37.7 / 71.4 us, 4 (127 registers, no spill) 35.1 / 64.4 us,
 // 5 (96 registers, spills) 46.2 / 93.6 us; at 2 048 games all three take 10.3 us.  The extension
@@ -458,42 +494,7 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
 #ifdef C4_PHASE_STAMPS
   if (lane == 0) for (int i = 9; i < 16; i++) p.phase[(size_t)blockIdx.x * 16 + i] = 0;
 #endif
-  if (blockIdx.x >= p.n_waves) {
-    // The extra workgroups a timed launch carries (they own no games; one per 1 024 wavefronts):
-    // duration of the PREVIOUS launch = last wavefront end - first wavefront start (its stamps are
-    // complete: kernel boundary).  Each helper reduces its chunk, the last one to finish adds the
-    // launch to the totals.  No game's critical path carries any of this.
-    if (p.seq <= 1) return;
-    const uint32_t h = blockIdx.x - p.n_waves, n_helpers = gridDim.x - p.n_waves;
-    const unsigned long long* prev = p.stamps + (size_t)((p.seq - 1) & 1) * p.n_waves * 2;
-    const uint32_t w_end = (h + 1) * kWavesPerTimingHelper < p.n_waves ? (h + 1) * kWavesPerTimingHelper : p.n_waves;
-    unsigned long long lo = ~0ull, hi = 0ull;
-#pragma unroll 8
-    for (uint32_t w = h * kWavesPerTimingHelper + lane; w < w_end; w += 64) {
-      const ulonglong2 ab = reinterpret_cast<const ulonglong2*>(prev)[w];
-      lo = ab.x < lo ? ab.x : lo;
-      hi = ab.y > hi ? ab.y : hi;
-    }
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned long long ol = ((unsigned long long)shfl_u32((uint32_t)(lo >> 32), (int)(lane ^ off)) << 32) | shfl_u32((uint32_t)lo, (int)(lane ^ off));
-      const unsigned long long oh = ((unsigned long long)shfl_u32((uint32_t)(hi >> 32), (int)(lane ^ off)) << 32) | shfl_u32((uint32_t)hi, (int)(lane ^ off));
-      lo = ol < lo ? ol : lo;
-      hi = oh > hi ? oh : hi;
-    }
-    if (lane == 0) {
-      unsigned long long* tmp = p.clock_acc + 2;   // [2] running min start, [3] running max end, [4] helpers done
-      atomicMin(&tmp[0], lo);
-      atomicMax(&tmp[1], hi);
-      __threadfence();
-      if (atomicAdd(&tmp[2], 1ull) == n_helpers - 1) {
-        __threadfence();
-        const unsigned long long first = atomicExch(&tmp[0], ~0ull), last = atomicExch(&tmp[1], 0ull);
-        atomicExch(&tmp[2], 0ull);
-        if (last > first) { p.clock_acc[0] += last - first; p.clock_acc[1] += 1; }
-      }
-    }
-    return;
-  }
+  if (blockIdx.x >= p.n_waves) { timing_helper(p, lane); return; }
 
   const uint32_t gs = g < p.n_slots ? g : 0;
   Slot* st = p.slots + gs;
@@ -1050,6 +1051,7 @@ struct c4_session {
   c4_config cfg{};
   Params p{};
   hipStream_t stream = nullptr;
+  uint32_t lanes_per_game = 8;   // c4_step_kernel's mapping (a 4-lane variant was built and measured: tools/experiments/)
   uint32_t n_waves = 0;       // wavefronts a step launches now (shrinks with c4_session_compact)
   uint32_t n_waves_cap = 0;   // as created: size of the per-wavefront arrays
   uint32_t seq = 0;
@@ -1107,7 +1109,9 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   if (bps > kMaxBlocksPerSlot) bps = kMaxBlocksPerSlot;   // n_mcts_iterations > 1523: overflow is still detected per slot
   s->cfg.blocks_per_slot = (uint32_t)bps;
   const size_t n = cfg->n_slots;
-  s->n_waves = s->n_waves_cap = (uint32_t)((n + 7) / 8);
+  const uint32_t games_per_wave = 64u / s->lanes_per_game;
+  s->n_waves = (uint32_t)((n + games_per_wave - 1) / games_per_wave);
+  s->n_waves_cap = (uint32_t)((n + 7) / 8);   // per-wavefront arrays are sized for the finer kernel
   Params& p = s->p;
   p.n_slots = cfg->n_slots;
   p.blocks_per_slot = (uint32_t)bps;
@@ -1123,11 +1127,11 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   hipError_t e;
   if ((e = hipMalloc(&p.slots, n * sizeof(Slot))) != hipSuccess ||
       (e = hipMalloc(&p.blocks, n * bps * sizeof(Block))) != hipSuccess ||
-      (e = hipMalloc(&p.wave_ctr, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMalloc(&p.wave_ctr, (size_t)s->n_waves_cap * CTR_N * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.glob, sizeof(Globals))) != hipSuccess ||
-      (e = hipMalloc(&p.stamps, (size_t)s->n_waves * 4 * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMalloc(&p.stamps, (size_t)s->n_waves_cap * 4 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.clock_acc, 5 * sizeof(unsigned long long))) != hipSuccess ||
-      (e = hipMalloc(&p.phase, ((size_t)s->n_waves + 64) * 16 * sizeof(unsigned long long))) != hipSuccess ||   // + the timing helper workgroups (diagnostic builds stamp them too)
+      (e = hipMalloc(&p.phase, ((size_t)s->n_waves_cap + 64) * 16 * sizeof(unsigned long long))) != hipSuccess ||   // + the timing helper workgroups (diagnostic builds stamp them too)
       (e = hipMalloc(&s->ln_tab_dev, (size_t)n_ln * sizeof(float))) != hipSuccess ||
       (e = hipHostMalloc(&s->probe_host, sizeof(Globals))) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s->probe_event, hipEventDisableTiming)) != hipSuccess)
@@ -1139,12 +1143,12 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   hipLaunchKernelGGL(k_ln_table, dim3((n_ln + 255) / 256), dim3(256), 0, nullptr, s->ln_tab_dev, n_ln);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemset(p.stamps, 0, (size_t)s->n_waves * 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(p.stamps, 0, (size_t)s->n_waves_cap * 4 * sizeof(unsigned long long)));
   HIP_TRY(reset_clock_acc(p.clock_acc));
-  HIP_TRY(hipMemset(p.phase, 0, ((size_t)s->n_waves + 64) * 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(p.phase, 0, ((size_t)s->n_waves_cap + 64) * 16 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(p.slots, 0, n * sizeof(Slot)));
   HIP_TRY(hipMemset(p.glob, 0, sizeof(Globals)));
-  HIP_TRY(hipMemset(p.wave_ctr, 0, (size_t)s->n_waves * CTR_N * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(p.wave_ctr, 0, (size_t)s->n_waves_cap * CTR_N * sizeof(unsigned long long)));
   memset(s->probe_host, 0, sizeof(Globals));
   return C4_OK;
 }
@@ -1220,7 +1224,7 @@ int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n
     HIP_TRY(hipMemcpy(s->start_value_dev, start_values, n_games * 8, hipMemcpyHostToDevice));
   }
   s->p.n_slots = s->cfg.n_slots;   // a compacted session goes back to its full width
-  s->n_waves = s->p.n_waves = s->n_waves_cap;
+  s->n_waves = s->p.n_waves = (s->cfg.n_slots + 64u / s->lanes_per_game - 1) / (64u / s->lanes_per_game);
   Globals g0{};
   g0.queue_head = n_games < s->cfg.n_slots ? n_games : s->cfg.n_slots;
   HIP_TRY(hipMemcpy(s->p.glob, &g0, sizeof g0, hipMemcpyHostToDevice));
@@ -1291,9 +1295,9 @@ int c4_session_start(c4_session* s) {
   if (!s->bound || !s->have_games) return fail(C4_ERR_NOT_BOUND, "bind_io and set_games must precede start");
   C4_ON_DEVICE(s->cfg.device);
   if (s->cfg.planes_dtype == 0)
-    hipLaunchKernelGGL(c4_start_kernel<float>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+    hipLaunchKernelGGL(c4_start_kernel<float>, dim3((s->p.n_slots + 7) / 8), dim3(64), 0, s->stream, s->p);
   else
-    hipLaunchKernelGGL(c4_start_kernel<uint16_t>, dim3(s->n_waves), dim3(64), 0, s->stream, s->p);
+    hipLaunchKernelGGL(c4_start_kernel<uint16_t>, dim3((s->p.n_slots + 7) / 8), dim3(64), 0, s->stream, s->p);
   HIP_TRY(hipGetLastError());
   return C4_OK;
 }
@@ -1314,13 +1318,19 @@ int c4_session_step(c4_session* s) {
   // a timed launch (seq != 0) carries extra workgroups that fold the previous launch's stamps
   const uint32_t helpers = s->p.seq ? (s->n_waves + kWavesPerTimingHelper - 1) / kWavesPerTimingHelper : 0u;
   auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(s->n_waves + helpers), dim3(64), lds_pad, s->stream, s->p); };
-  if (s->cfg.planes_dtype == 0) {
-    if (noise) { if (cache) launch(c4_step_kernel<float, true, true>); else launch(c4_step_kernel<float, true, false>); }
-    else       { if (cache) launch(c4_step_kernel<float, false, true>); else launch(c4_step_kernel<float, false, false>); }
-  } else {
-    if (noise) { if (cache) launch(c4_step_kernel<uint16_t, true, true>); else launch(c4_step_kernel<uint16_t, true, false>); }
-    else       { if (cache) launch(c4_step_kernel<uint16_t, false, true>); else launch(c4_step_kernel<uint16_t, false, false>); }
-  }
+  const bool f32 = s->cfg.planes_dtype == 0;
+#define C4_LAUNCH_STEP(KERNEL)                                                                                       \
+  do {                                                                                                               \
+    if (f32) {                                                                                                       \
+      if (noise) { if (cache) launch(KERNEL<float, true, true>); else launch(KERNEL<float, true, false>); }          \
+      else       { if (cache) launch(KERNEL<float, false, true>); else launch(KERNEL<float, false, false>); }        \
+    } else {                                                                                                         \
+      if (noise) { if (cache) launch(KERNEL<uint16_t, true, true>); else launch(KERNEL<uint16_t, true, false>); }    \
+      else       { if (cache) launch(KERNEL<uint16_t, false, true>); else launch(KERNEL<uint16_t, false, false>); }  \
+    }                                                                                                                \
+  } while (0)
+  C4_LAUNCH_STEP(c4_step_kernel);
+#undef C4_LAUNCH_STEP
   HIP_TRY(hipGetLastError());
   return C4_OK;
 }
@@ -1424,7 +1434,7 @@ int c4_session_compact(c4_session* s, uint32_t multiple, uint32_t* n_active, uin
   if (want < multiple) want = multiple;
   if (want < s->p.n_slots) {
     s->p.n_slots = want;
-    s->n_waves = (want + 7) / 8;
+    s->n_waves = (want + 64u / s->lanes_per_game - 1) / (64u / s->lanes_per_game);
     s->p.n_waves = s->n_waves;
     HIP_TRY(hipMemset(s->p.stamps, 0, (size_t)s->n_waves_cap * 4 * sizeof(unsigned long long)));   // the stamp stride changed
   }
