@@ -255,3 +255,43 @@ def test_cbor_round_trip_property():
                     assert np.float32(s.q_no_penalty).tobytes() == np.float32(t.q_no_penalty).tobytes()
 
     check()
+
+
+def test_merge_parts_restores_request_order_numpy_and_torch():
+    """c4a0_amd.api.merge_parts (used for concurrent sessions and for the multi-GPU shard merge): parts
+    that own interleaved request positions come back in request order, numpy records and torch uint8
+    rows alike, including empty parts and games without samples."""
+    import torch
+    from c4a0_amd.api import merge_parts
+    from c4a0_amd.session import SAMPLE_DTYPE
+
+    rng = np.random.default_rng(3)
+    n = 53
+    counts = rng.integers(0, 6, size=n).astype(np.uint32)
+    recs = np.zeros(int(counts.sum()), dtype=SAMPLE_DTYPE)
+    recs["game_id"] = np.repeat(np.arange(n, dtype=np.uint64), counts)
+    recs["meta"] = np.concatenate([np.arange(c, dtype=np.uint32) for c in counts]) if counts.sum() else []
+    recs["mask"] = rng.integers(0, 1 << 42, size=len(recs)).astype(np.uint64)
+    offs = np.concatenate([[0], np.cumsum(counts.astype(np.int64))])
+    for k in (1, 2, 3, 8, 60):     # 60 > n: some parts own nothing
+        parts_np, parts_t = [], []
+        for p in range(k):
+            pos = np.arange(p, n, k, dtype=np.int64)
+            r = np.concatenate([recs[offs[g]:offs[g + 1]] for g in pos]) if len(pos) else recs[:0]
+            parts_np.append((pos, counts[pos], r))
+            parts_t.append((pos, counts[pos], torch.from_numpy(r.view(np.uint8).reshape(-1, 64).copy())))
+        got, got_counts = merge_parts(n, parts_np)
+        assert np.array_equal(got_counts, counts) and got.tobytes() == recs.tobytes()
+        got_t, got_counts_t = merge_parts(n, parts_t)
+        assert np.array_equal(got_counts_t, counts) and got_t.numpy().tobytes() == recs.tobytes()
+
+
+def test_to_records_round_trip():
+    from c4a0_amd.results import results_from_records
+    pgr, _ = _mk()
+    recs, counts = pgr.to_records()
+    assert counts.tolist() == [len(r.samples) for r in pgr.results] and len(recs) == counts.sum()
+    back = results_from_records([r.metadata for r in pgr.results], recs, counts)
+    assert back == pgr
+    r2, c2 = back.to_records()      # the lazy form hands the arrays straight back
+    assert r2.tobytes() == recs.tobytes() and np.array_equal(c2, counts)

@@ -331,3 +331,61 @@ def test_second_device_after_the_first():
         out.append(c4a0_amd.play_games(reqs, 64, 8, 6.6, 0.01, evaluator=net, device=dev, resident_games=8).to_records())
         assert torch.cuda.current_device() == before
     assert out[0][0].tobytes() == out[1][0].tobytes()
+
+
+def test_device_callback_wrapper_plays_in_device_mode_with_the_callers_call_unchanged():
+    """An unmodified caller passes a callback (training.py:179-189).  A `DeviceCallback` in its place
+    answers numpy batches like `forward_numpy` AND is recognised by play_games, which then keeps the
+    leaves in HBM: same samples as `evaluator=`, and the callback itself is never invoked."""
+    import c4a0_amd
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(21)
+    net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 2, 2)), dev, dtype=torch.bfloat16)
+    calls = []
+
+    class Spy(c4a0_amd.DeviceCallback):
+        def __call__(self, model_id, x):
+            calls.append(x.shape[0])
+            return super().__call__(model_id, x)
+
+    reqs = [c4a0_amd.GameMetadata(300 + i, 0, 0) for i in range(20)]
+    cb = Spy(net, dev)
+    via_cb = c4a0_amd.play_games(reqs, 64, 8, 6.6, 0.01, cb, resident_games=16)          # the reference's six positional arguments
+    direct = c4a0_amd.play_games(reqs, 64, 8, 6.6, 0.01, evaluator=net, resident_games=16)
+    assert calls == [] and via_cb.to_records()[0].tobytes() == direct.to_records()[0].tobytes()
+    lp, qp, qn = cb(0, np.zeros((3, 2, 6, 7), dtype=np.float32))                          # and it still is a numpy callback
+    assert lp.shape == (3, 7) and qp.shape == (3,) and qn.shape == (3,) and lp.dtype == np.float32 and calls == [3]
+
+
+def test_leaf_keys_identify_positions():
+    """c4_session_leaf_keys: value bits | column heights << 42 per active slot, -1 for idle slots: equal
+    keys <=> equal (mask, value)."""
+    import ctypes as C
+    from c4a0_amd._lib import check
+    from c4a0_amd.session import DeviceSession
+    from tests.helpers import hash_eval_torch
+
+    s = DeviceSession(64, 12, 6.6, 0.01)
+    s.set_games([(i, 0, 0) for i in range(40)])     # 24 idle slots
+    s.bind()
+    s.start()
+    keys = torch.zeros(64, dtype=torch.int64, device=s.device)
+    for _ in range(30):
+        s.evaluate(hash_eval_torch)
+        s.step()
+    check(s.L.c4_session_leaf_keys(s._h, C.c_void_p(keys.data_ptr())))
+    torch.cuda.synchronize()
+    mask, value, status = s.leaves()
+    k = keys.cpu().numpy()
+    s.close()
+    for g in range(64):
+        if status[g] != 1:
+            assert k[g] == -1
+            continue
+        heights = sum(bin(int(mask[g]) & (0x810204081 << c)).count("1") << (3 * c) for c in range(7))
+        assert int(k[g]) == int(value[g]) | (heights << 42)
+    act = status == 1
+    pos = {(int(m), int(v)) for m, v in zip(mask[act], value[act])}
+    assert len(pos) == len(set(k[act].tolist()))
