@@ -372,7 +372,12 @@ def main():
             allgather = {"error": repr(e)}
 
     games, sims, elapsed_max = float(d["games_done"]), float(d["sims"]), elapsed
+    per_rank = None
     if dist is not None:
+        mine = torch.tensor([games, elapsed], dtype=torch.float64, device=red_dev)   # per-rank view, for reading the scaling curve
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"games_completed": [float(x[0]) for x in allr], "elapsed_s": [float(x[1]) for x in allr]}
         t = torch.tensor([games, sims, float(d["ref_skipped_sims"])], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         m = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -449,6 +454,8 @@ def main():
         }
         if allgather is not None:
             out["sample_allgather"] = allgather
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             # the checker's leg runs in a child process under a time limit: whatever happens to it, the GPU line is printed
             import subprocess
