@@ -70,41 +70,62 @@ def cpu_baseline(net, device, n_iter: int, threads: int, budget_s: float = 20.0)
     NN thread (NNThread::loop_until_close: drain the queue, batch the unique leaves, call the
     evaluator), `threads - 1` C worker threads are the MctsThreads, games travel over two queues, so
     network evaluation and tree work overlap (oracle c4o_self_play_async).  The evaluator is the SAME
-    bf16 network on the GPU through the numpy callback round trip of nn.py:119-130.  Bounded sample of
-    the same workload: a small probe sizes the sample to about `budget_s` seconds."""
+    bf16 network on the GPU through the numpy callback round trip of nn.py:119-130.
+
+    Reported as the MEDIAN of >= 3 equal samples of the same workload (with min / max / n): a probe
+    sizes the sample so that the three together take about `budget_s` seconds.  The NN thread keeps
+    one core to itself and the workers are pinned one per core over the others
+    (c4o_set_thread_pinning): 15 spinning workers preempting the thread that feeds them is what made
+    the single-sample figure of round 2 move by +-25 % run to run."""
     from oracle import c4oracle as O
 
+    cb_time = [0.0]
+
     def cb(_model_id, x):
+        t = time.perf_counter()
         with torch.no_grad():
             lp, q = net(torch.from_numpy(x).to(device))
             lp, q = lp.float().cpu().numpy(), q.float().cpu().numpy()
-        return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
+        out = np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
+        cb_time[0] += time.perf_counter() - t
+        return out
 
     threads = max(2, threads)
+    O.lib().c4o_set_thread_pinning(1)
 
     def run(n_games, topology="async"):
         reqs = [(i, 0, 0) for i in range(n_games)]
+        cb_time[0] = 0.0
         t0 = time.perf_counter()
         _res, st = O.self_play(reqs, 4096, n_iter, 6.6, 0.01, cb, n_threads=threads, topology=topology)
-        return time.perf_counter() - t0, st
+        dt = time.perf_counter() - t0
+        return dt, st, cb_time[0] / dt
 
-    # grow the sample until it runs for >= budget_s / 2 (all games resident at once, as in the
-    # reference, so the evaluator batches grow with the sample)
-    n_games, (dt, st) = 256, run(256)
-    while dt < budget_s / 2 and n_games < 32768:
-        n_games *= 2 if dt > budget_s / 8 else 4
-        dt, st = run(n_games)
+    # size the sample: all games resident at once, as in the reference, so the evaluator batches grow with it
+    n_samples = 3
+    n_games, (dt, st, share) = 256, run(256)
+    while dt < budget_s / (2 * n_samples) and n_games < 32768:
+        n_games *= 2 if dt > budget_s / (8 * n_samples) else 4
+        dt, st, share = run(n_games)
+    runs = [(dt, st, share)] + [run(n_games) for _ in range(n_samples - 1)]
+    rates = sorted(n_games / r[0] for r in runs)
+    med_i = sorted(range(len(runs)), key=lambda i: runs[i][0])[len(runs) // 2]
+    dt, st, share = runs[med_i]
     # context 1: the round-1 restatement (lock-step ticks: evaluation and tree work serialised) on a quarter of the sample
-    dt_l, _st_l = run(max(256, n_games // 4), topology="lockstep")
+    dt_l, _st_l, _ = run(max(256, n_games // 4), topology="lockstep")
     # context 2: the tree path alone on the host cores (uniform evaluator, no network at all)
     t0 = time.perf_counter()
     _r, st_u = O.self_play([(i, 0, 0) for i in range(2048)], 4096, n_iter, 6.6, 0.01, "uniform", n_threads=threads, topology="async")
     tree_only = st_u["sims"] / (time.perf_counter() - t0)
-    return {"value": n_games / dt, "unit": "games/s", "cores": threads, "kind": "port",
-            "topology": f"async: 1 evaluator thread + {threads - 1} MCTS worker threads over two queues, evaluation and tree work overlapped (self_play.rs:60-106)",
+    O.lib().c4o_set_thread_pinning(0)
+    return {"value": rates[len(rates) // 2], "min": rates[0], "max": rates[-1], "n": len(rates), "unit": "games/s", "cores": threads, "kind": "port",
+            "topology": f"async: 1 evaluator thread (own core) + {threads - 1} MCTS worker threads pinned over the other cores, two queues, "
+                        "evaluation and tree work overlapped (self_play.rs:60-106)",
+            "evaluator_callback_share_of_wall": share,
             "tree_only_sims_per_s": tree_only, "lockstep_games_per_s": max(256, n_games // 4) / dt_l,
             "nn_calls": st["nn_calls"], "mean_nn_batch": st["nn_positions"] / max(1, st["nn_calls"]),
-            "sample": f"{n_games} games, n_mcts_iterations={n_iter}, C oracle in the reference's thread topology ({threads} threads) + the same bf16 ResNet on the GPU via the numpy callback round trip; {dt:.1f} s",
+            "sample": f"median of {len(rates)} runs of {n_games} games each, n_mcts_iterations={n_iter}, C oracle in the reference's thread topology "
+                      f"({threads} threads) + the same bf16 ResNet on the GPU via the numpy callback round trip; {dt:.1f} s per run",
             "sims_per_s": st["sims"] / dt}
 
 
@@ -146,6 +167,58 @@ def whole_job(args, device, real_stdout):
             "config": {"workload": f"src/c4a0/main.py:40-51 defaults: {n_games} games, n_mcts_iterations={n_iter}, max_nn_batch_size=2000, 1-block/32-ch ResNet (4 policy / 2 value layers) bf16"},
             **out}
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
+
+def launch_ranks(n: int, real_stdout: int) -> int:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N rank processes here, one
+    per GPU, exactly as `torch.distributed.run --nproc-per-node N` would (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*), relay rank 0's JSON line and return the worst exit code.  The children are FRESH processes
+    created before this one has made any GPU call (never a re-exec of a process that initialised the GPU);
+    if a rank dies the others are stopped (by pid) instead of waiting in a barrier for ever."""
+    import socket
+    import subprocess
+    import tempfile
+
+    if os.environ.get("C4_BENCH_SAME_DEVICE") != "1":
+        have = torch.cuda.device_count()          # counts devices without initialising one
+        if n > have:
+            sys.stderr.write(f"bench.py: --gpus {n} but only {have} device(s) visible\n")
+            return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs, outs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = tempfile.TemporaryFile() if r == 0 else subprocess.DEVNULL
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, cwd=os.getcwd()))
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        time.sleep(0.2)
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):      # a rank failed: the others would block in their next collective
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = p.wait(timeout=30)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[i] = p.wait()
+    outs[0].seek(0)
+    lines = [l for l in outs[0].read().decode(errors="replace").splitlines() if l.startswith("{")]
+    for l in lines:
+        os.write(real_stdout, (l + "\n").encode())
+    worst = max(abs(rc) for rc in rcs)
+    return worst if worst else (0 if lines else 1)
 
 
 def main():
@@ -198,9 +271,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process becomes one (it has not touched the GPU yet, and never will)
+        sys.exit(launch_ranks(args.gpus, real_stdout))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device")

@@ -27,10 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <map>
-#include <mutex>
 #include <string>
-#include <utility>
 
 #include "../../include/c4a0_hip.h"
 #include "c4_host.hpp"
@@ -302,24 +299,11 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   }
 }
 
-// More than 64 KB of dynamic LDS needs an opt-in per kernel AND per device (hipFuncSetAttribute
-// acts on the current device's function object): remembered per (kernel, device).
-hipError_t opt_in_lds(const void* kernel, int bytes, int device) {
-  static std::mutex mu;
-  static std::map<std::pair<const void*, int>, bool> done;
-  std::lock_guard<std::mutex> lock(mu);
-  const auto key = std::make_pair(kernel, device);
-  if (done.count(key)) return hipSuccess;
-  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e == hipSuccess) done[key] = true;
-  return e;
-}
-
 template <int C, int NB, int NT, int A, int B>
 int launch_tower(const TowerParams& p, uint32_t n_boards, hipStream_t stream, int device) {
   constexpr int kLds = Geo<C, NB>::kLdsBytes;
   auto k = c4_conv_tower_kernel<C, NB, NT, A, B>;
-  hipError_t e = opt_in_lds((const void*)k, kLds, device);
+  hipError_t e = c4host::opt_in_lds((const void*)k, kLds, device);
   if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: LDS opt-in (") + std::to_string(kLds) + " bytes) on device " + std::to_string(device) + ": " + hipGetErrorString(e));
   k<<<dim3((n_boards + NB - 1) / NB), dim3(NT), kLds, stream>>>(p);
   e = hipGetLastError();

@@ -1,0 +1,255 @@
+// c4_head_gemm.hip -- the hidden layers of ConnectFourNet's two heads (reference src/c4a0/nn.py:75-100:
+// Linear(F, F) + BatchNorm1d + ReLU, BN folded) as a hand-written bf16 MFMA GEMM for gfx950:
+//
+//     Y[M, N] = act(X[M, K] . W[N, K]^T + bias[N])        X, W, Y bf16; accumulation and bias in f32
+//
+// Why not the library GEMM: the evaluator must be a FUNCTION OF THE POSITION.  hipBLASLt picks its
+// kernel (tile, MFMA shape, stream-K split) from M, so the low bits of a position's outputs depended
+// on the batch it sat in and on its row -- and with them the samples of a whole play_games call
+// (callback mode vs device mode, resident_games, concurrent sessions, tail narrowing).  Here every
+// output element is ONE fixed chain: k-tiles ascending, two v_mfma_f32_16x16x32_bf16 per 64-deep
+// k-tile, no split-K, no atomics -- the same bits whatever M, whatever row, whichever tile
+// configuration below computes it (the configurations differ in what a workgroup owns, never in an
+// element's summation order).
+//
+// Mapping: D[n][m] = sum_k W[n][k] X[m][k] -- the weights are the MFMA's A operand, the activations its
+// B operand, so a lane ends up with 4 consecutive output features of one board: one 8-byte store.
+// A workgroup owns a BM x BN tile of Y; X and W k-tiles (64 deep = 128-byte rows) stream global -> LDS
+// by direct-to-LDS DMA (global_load_lds_dwordx4, 1 KB per wave-instruction) into an NSTAGE ring; the
+// 16-byte slot of k-group g of row r lives at slot g ^ (r & 7) (the XOR goes on the per-lane SOURCE
+// address, the LDS image stays lane-linear), which makes every ds_read_b128 of a fragment bank-conflict
+// free.  One raw s_barrier per k-tile, counted vmcnt waits: loads stay in flight across barriers.
+// The default configuration keeps a workgroup at 4 wavefronts / 80 KB so that TWO share a CU: one's
+// prologue, barriers and epilogue run under the other's MFMAs (the kernels of the other session's
+// stream are what usually sits beside it).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/c4a0_hip.h"
+#include "c4_host.hpp"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;   // k-tile depth: 128-byte rows in LDS
+
+struct GemmParams {
+  const uint16_t* x;     // [M][ldx]
+  const uint16_t* w;     // [N][K]
+  const float* bias;     // [N]
+  uint16_t* y;           // [M][ldy]
+  uint32_t M, N, K, ldx, ldy, relu;
+  uint32_t tiles_m, tiles_n;
+  uint32_t xm, xn;       // XCD rectangle grid (xm * xn == 8), 0 = plain row-major tile order
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmParams p) {
+  constexpr int kWaves = WM * WN;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;        // 16 x 16 output tiles per wavefront
+  constexpr int kStageBytes = (BM + BN) * BK * 2;
+  constexpr int kChunks = (BM + BN) / 8;                      // 1 KB DMA pieces (8 rows x 128 bytes) per k-tile
+  constexpr int L = kChunks / kWaves;                         // pieces per wavefront per k-tile
+  static_assert(kChunks % kWaves == 0, "every wavefront issues the same number of loads per k-tile (counted waits)");
+  static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "wave tiles are multiples of 16");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+  extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int li = lane & 15, lg = lane >> 4;
+
+  // ---- which tile: blocks b and b + 8 share an XCD (round-robin dispatch; speed only).  Give each
+  // XCD a rectangle of tiles so that its private L2 sees each X row block and W column block once.
+  int tm, tn;
+  {
+    const int b = blockIdx.x;
+    if (p.xm) {
+      const int rm = p.tiles_m / p.xm, rn = p.tiles_n / p.xn;
+      const int xcd = b & 7, idx = b >> 3;
+      tm = (xcd / (int)p.xn) * rm + idx / rn;
+      tn = (xcd % (int)p.xn) * rn + idx % rn;
+    } else {
+      tm = b / (int)p.tiles_n;
+      tn = b % (int)p.tiles_n;
+    }
+  }
+  const int tm0 = tm * BM, tn0 = tn * BN;
+
+  // ---- DMA source offsets (bytes from x / w) of this lane for its L pieces of a k-tile; a k-tile
+  // later they are 128 bytes further.  Piece c < BM/8 is rows 8c..8c+7 of the X tile, else of the W tile.
+  // Lane l of a piece fills LDS bytes 16 l..16 l + 15 = row l >> 3, slot l & 7 = k-group (l & 7) ^ (row & 7).
+  uint32_t src_off[L];
+  const int r8 = lane >> 3, slot = lane & 7;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    const int c = wave + kWaves * i;
+    if (c < BM / 8) {
+      const int row = c * 8 + r8;
+      int gr = tm0 + row;
+      gr = gr < (int)p.M ? gr : (int)p.M - 1;                  // rows past the end re-read the last one (never stored)
+      src_off[i] = (uint32_t)gr * p.ldx * 2u + (uint32_t)((slot ^ (row & 7)) * 16);
+    } else {
+      const int row = (c - BM / 8) * 8 + r8;
+      src_off[i] = (uint32_t)(tn0 + row) * p.K * 2u + (uint32_t)((slot ^ (row & 7)) * 16);
+    }
+  }
+  // buffer_load ... lds (MUBUF): descriptor + 32-bit per-lane offset + the k-tile's scalar offset.  (The
+  // flat-encoded global_load_lds makes hipcc treat every later LDS wait as lgkmcnt(0); the MUBUF form
+  // counts on vmcnt only, so the fragment reads below get counted lgkmcnt waits.)
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.M * p.ldx * 2u), 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(p.N * p.K * 2u), 0x00020000);
+  auto issue = [&](int kt) __attribute__((always_inline)) {
+    uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const int c = wave + kWaves * i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((c < BM / 8) ? x_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)(st + c * 1024), 16,
+                                               (int)src_off[i], kt * (BK * 2), 0, 0);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; a++)
+#pragma unroll
+    for (int b = 0; b < TM; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets inside a stage: row = tile base (a multiple of 16) + li, so row & 7 == li & 7
+  const uint32_t frag_off0 = (uint32_t)li * 128u + (uint32_t)(((0 + lg) ^ (li & 7)) * 16);
+  const uint32_t frag_off1 = (uint32_t)li * 128u + (uint32_t)(((4 + lg) ^ (li & 7)) * 16);
+  const uint32_t x_base = (uint32_t)(wm * (BM / WM)) * 128u;
+  const uint32_t w_base = (uint32_t)(BM * BK * 2) + (uint32_t)(wn * (BN / WN)) * 128u;
+
+  const int KT = (int)p.K / BK;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; s++)
+    if (s < KT) issue(s);
+
+  for (int kt = 0; kt < KT; kt++) {
+    // k-tile kt must have landed; up to NSTAGE - 2 younger ones may stay in flight
+    const int rem = KT - 1 - kt;
+    const int younger = rem < NSTAGE - 2 ? rem : NSTAGE - 2;
+    if (NSTAGE >= 4 && younger == 2) wait_vmcnt<2 * L>();
+    else if (NSTAGE >= 3 && younger == 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                               // everybody's pieces of kt landed; everybody left buffer (kt - 1) % NSTAGE
+    if (kt + NSTAGE - 1 < KT) issue(kt + NSTAGE - 1);
+    const uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
+    // Fragment reads of the first 32-deep half are requested up front (activations first: the first
+    // MFMAs need all TM of them and one weight fragment); the second half's reads are issued between
+    // the first half's MFMAs, so that at most ~14 LDS reads are outstanding (the counter holds 15)
+    // and the MFMAs of a half never wait for more than the fragments they use.
+    bf16x8 afr[2][TN], bfr[2][TM];
+    auto rd_x = [&](int kk, int b) __attribute__((always_inline)) {
+      bfr[kk][b] = *reinterpret_cast<const bf16x8*>(st + x_base + (kk ? frag_off1 : frag_off0) + b * 2048);
+    };
+    auto rd_w = [&](int kk, int a) __attribute__((always_inline)) {
+      afr[kk][a] = *reinterpret_cast<const bf16x8*>(st + w_base + (kk ? frag_off1 : frag_off0) + a * 2048);
+    };
+#pragma unroll
+    for (int b = 0; b < TM; b++) rd_x(0, b);
+#pragma unroll
+    for (int a = 0; a < TN; a++) rd_w(0, a);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int kPerStep = (TN + TM + TN - 1) / TN;           // second-half reads issued behind each weight row's MFMAs
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+#pragma unroll
+      for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0][a], bfr[0][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int r = a * kPerStep; r < (a + 1) * kPerStep && r < TN + TM; r++) {
+        if (r < TM) rd_x(1, r); else rd_w(1, r - TM);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int a = 0; a < TN; a++)
+#pragma unroll
+      for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue: lane holds features n0 + 4 lg + {0..3} of board m (C/D map: row = 4 (lane >> 4) + reg, col = lane & 15)
+#pragma unroll
+  for (int a = 0; a < TN; a++) {
+    const int n = tn0 + wn * (BN / WN) + a * 16 + 4 * lg;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int b = 0; b < TM; b++) {
+      const int m = tm0 + wm * (BM / WM) + b * 16 + li;
+      f32x4 v = acc[a][b] + bv;
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+      }
+      const bf16x4 o = __builtin_convertvector(v, bf16x4);
+      if (m < (int)p.M) *reinterpret_cast<uint2*>(p.y + (size_t)m * p.ldy + n) = __builtin_bit_cast(uint2, o);
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW>
+int launch_gemm(GemmParams p, hipStream_t stream, int device) {
+  constexpr int kLds = NSTAGE * (BM + BN) * BK * 2;
+  auto k = c4_head_gemm_kernel<BM, BN, WM, WN, NSTAGE, MINW>;
+  if (kLds > 64 * 1024) {
+    const hipError_t e = c4host::opt_in_lds((const void*)k, kLds, device);
+    if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16: LDS opt-in: ") + hipGetErrorString(e));
+  }
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = p.N / BN;
+  // XCD rectangles: of the factorizations of 8 that divide the tile grid, the one whose rectangle
+  // pulls the fewest operand rows into an XCD's L2
+  p.xm = p.xn = 0;
+  uint64_t best = ~0ull;
+  for (uint32_t xm = 1; xm <= 8; xm *= 2) {
+    const uint32_t xn = 8 / xm;
+    if (p.tiles_m % xm || p.tiles_n % xn) continue;
+    const uint64_t rows = (uint64_t)(p.tiles_m / xm) * BM + (uint64_t)(p.tiles_n / xn) * BN;
+    if (rows < best) { best = rows; p.xm = xm; p.xn = xn; }
+  }
+  k<<<dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), kLds, stream>>>(p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16 launch: ") + hipGetErrorString(e));
+  return C4_OK;
+}
+
+}  // namespace
+
+extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float* bias_dev, void* y_dev, uint32_t m, uint32_t n,
+                              uint32_t k, uint32_t ldx, uint32_t ldy, uint32_t relu, uint32_t config, void* stream) {
+  if (!x_dev || !w_dev || !bias_dev || !y_dev) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: null argument");
+  if (k == 0 || k % BK) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: K must be a positive multiple of 64");
+  if (n == 0 || n % 192) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: N must be a positive multiple of 192 (42 x C features, C a multiple of 32)");
+  if (ldx < k || ldy < n || ldx % 8 || ldy % 4) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: row strides must cover a row and keep 16-byte (x) / 8-byte (y) alignment");
+  if ((uint64_t)m * ldx * 2 >= (1ull << 32) || (uint64_t)n * k * 2 >= (1ull << 32)) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: operands are addressed with 32-bit byte offsets (< 4 GiB each)");
+  if (m == 0) return C4_OK;
+  const int device = c4host::stream_device((hipStream_t)stream);
+  c4host::DeviceGuard guard(device);
+  if (guard.error() != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16: hipSetDevice: ") + hipGetErrorString(guard.error()));
+  GemmParams p{(const uint16_t*)x_dev, (const uint16_t*)w_dev, bias_dev, (uint16_t*)y_dev, m, n, k, ldx, ldy, relu, 0, 0, 0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  if (config == 0) config = m <= 512 ? 9 : 1;
+  switch (config) {
+    case 1: return launch_gemm<128, 192, 2, 2, 2, 2>(p, st, device);   // 4 wavefronts (64 x 96 each), 80 KB: two workgroups per CU
+    case 2: return launch_gemm<128, 192, 2, 4, 4, 1>(p, st, device);   // 8 wavefronts (64 x 48), 4-deep ring, the whole LDS
+    case 3: return launch_gemm<256, 192, 2, 4, 2, 1>(p, st, device);   // 8 wavefronts (128 x 48), 112 KB
+    case 4: return launch_gemm<128, 96, 2, 2, 2, 2>(p, st, device);    // 4 wavefronts (64 x 48), 56 KB
+    case 5: return launch_gemm<64, 192, 1, 4, 2, 2>(p, st, device);    // 4 wavefronts (64 x 48), 64 KB
+    case 6: return launch_gemm<128, 192, 2, 2, 3, 1>(p, st, device);   // 4 wavefronts, 3-deep ring, 120 KB: one workgroup per CU
+    case 7: return launch_gemm<256, 192, 4, 2, 2, 1>(p, st, device);   // 8 wavefronts (64 x 96), 112 KB
+    case 8: return launch_gemm<128, 96, 2, 2, 4, 1>(p, st, device);    // 4 wavefronts (64 x 48), 4-deep ring, 112 KB
+    case 9: return launch_gemm<64, 96, 2, 2, 4, 2>(p, st, device);     // 4 wavefronts (32 x 48), 80 KB: small batches
+    default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
+  }
+}

@@ -2,7 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 
 namespace c4host {
 
@@ -36,6 +39,19 @@ inline int stream_device(hipStream_t stream) {
   if (stream != nullptr && hipStreamGetDevice(stream, &dev) != hipSuccess) dev = -1;
   if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = -1;
   return dev;
+}
+
+// More than 64 KB of dynamic LDS needs an opt-in per kernel AND per device (hipFuncSetAttribute
+// acts on the current device's function object): remembered per (kernel, device).
+inline hipError_t opt_in_lds(const void* kernel, int bytes, int device) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, bool> done;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(kernel, device);
+  if (done.count(key)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done[key] = true;
+  return e;
 }
 
 }  // namespace c4host

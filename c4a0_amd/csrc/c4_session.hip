@@ -1106,7 +1106,6 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   uint64_t bps = cfg->blocks_per_slot;
   if (bps == 0) bps = 43ull * (cfg->n_mcts_iterations ? cfg->n_mcts_iterations : 1) + 8;
   if (bps < 2) bps = 2;
-  if (bps > kMaxBlocksPerSlot) bps = kMaxBlocksPerSlot;   // n_mcts_iterations > 1523: overflow is still detected per slot
   s->cfg.blocks_per_slot = (uint32_t)bps;
   const size_t n = cfg->n_slots;
   const uint32_t games_per_wave = 64u / s->lanes_per_game;
@@ -1159,14 +1158,16 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
   if (cfg->n_slots == 0) return fail(C4_ERR_BAD_ARG, "n_slots must be > 0");
   if (cfg->planes_dtype > 1) return fail(C4_ERR_BAD_ARG, "planes_dtype must be 0 (f32) or 1 (bf16)");
   if (cfg->blocks_per_slot > kMaxBlocksPerSlot) return fail(C4_ERR_BAD_ARG, "blocks_per_slot is limited to 65535 (16-bit child links)");
-  // A game's arena is never reclaimed while it is played: it needs about 0.9 blocks per simulation,
-  // i.e. up to ~40 x n_mcts_iterations for the longest games.  Beyond 1523 iterations the worst case
-  // (43 n + 8) no longer fits 16-bit links and the arena is capped at 65535 blocks, which still
-  // covers every game up to about 2000 iterations; past that a long game would overflow its arena
-  // (C4_ERR_ARENA_OVERFLOW) in the middle of a job, so it is refused here, with the reason.
-  if (cfg->blocks_per_slot == 0 && cfg->n_mcts_iterations > 2048)
-    return fail(C4_ERR_BAD_ARG, "n_mcts_iterations > 2048 is not supported: a game's tree arena is limited to 65535 blocks "
-                                "(16-bit child links, ~0.9 blocks per simulation, never reclaimed during a game)");
+  // A game's arena is never reclaimed while it is played: every expansion of the whole game takes one
+  // block, at most n_mcts_iterations per move and 42 moves, so 43 n + 8 blocks always suffice.  That
+  // provable bound fits the 16-bit child links up to n = 1523 (the reference's own sweep tops out at
+  // 1 500, src/c4a0/main.py:176).  Beyond it a long game could overflow its arena in the middle of a
+  // job (C4_ERR_ARENA_OVERFLOW loses the whole call), so the default sizing is refused here, with the
+  // reason; a caller who knows its games are short may still pass blocks_per_slot explicitly.
+  if (cfg->blocks_per_slot == 0 && 43ull * cfg->n_mcts_iterations + 8 > kMaxBlocksPerSlot)
+    return fail(C4_ERR_BAD_ARG, "n_mcts_iterations > 1523 is not supported with the default arena: a game's tree arena is limited to "
+                                "65535 blocks (16-bit child links; up to 43 n + 8 blocks per game, never reclaimed during a game). "
+                                "Pass blocks_per_slot explicitly to accept C4_ERR_ARENA_OVERFLOW on long games");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(C4_ERR_NO_DEVICE, "no HIP device visible");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(C4_ERR_BAD_ARG, "device ordinal out of range");
@@ -1246,6 +1247,29 @@ int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n
 
 int c4_session_bind_io(c4_session* s, void* planes_dev, const float* logprobs_dev, const float* q_dev, void* stream) {
   if (!s || !planes_dev || !logprobs_dev || !q_dev) return fail(C4_ERR_BAD_ARG, "null argument");
+  // the tensors and the stream must live on the session's device: a pointer of another device (or of
+  // the host) would only fault later, inside a kernel, far from its cause
+  C4_ON_DEVICE(s->cfg.device);
+  const struct { const void* ptr; const char* name; } io[3] = {{planes_dev, "planes_dev"}, {logprobs_dev, "logprobs_dev"}, {q_dev, "q_dev"}};
+  for (const auto& t : io) {
+    hipPointerAttribute_t attr{};
+    const hipError_t e = hipPointerGetAttributes(&attr, t.ptr);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(C4_ERR_BAD_ARG, std::string("c4_session_bind_io: ") + t.name + " is not a device pointer known to HIP (" + hipGetErrorString(e) + ")");
+    }
+    if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)
+      return fail(C4_ERR_BAD_ARG, std::string("c4_session_bind_io: ") + t.name + " is not device memory");
+    if (attr.type == hipMemoryTypeDevice && attr.device != s->cfg.device)
+      return fail(C4_ERR_BAD_ARG, std::string("c4_session_bind_io: ") + t.name + " lives on device " + std::to_string(attr.device) +
+                                      ", the session on device " + std::to_string(s->cfg.device));
+  }
+  if (stream != nullptr) {
+    int sdev = -1;
+    if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && sdev >= 0 && sdev != s->cfg.device)
+      return fail(C4_ERR_BAD_ARG, "c4_session_bind_io: the stream belongs to device " + std::to_string(sdev) + ", the session to device " +
+                                      std::to_string(s->cfg.device));
+  }
   s->p.planes = planes_dev;
   s->p.logprobs = logprobs_dev;
   s->p.q = q_dev;
@@ -1579,12 +1603,16 @@ int c4_session_leaves(c4_session* s, uint64_t* masks_host, uint64_t* values_host
 }
 
 // ---- element-wise entry points ----
+// They run on the device their stream belongs to (the caller's current device for the null stream) and
+// leave the caller's current device as they found it, like the session entry points.
 static inline dim3 grid_for(uint64_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+#define C4_ON_STREAM_DEVICE(stream) C4_ON_DEVICE(c4host::stream_device((hipStream_t)(stream)))
 
 int c4_pos_ops(const uint64_t* mask_dev, const uint64_t* value_dev, const int32_t* col_dev, uint64_t n, float c_ply_penalty,
                uint64_t* out_mask_dev, uint64_t* out_value_dev, uint32_t* out_legal_dev, uint32_t* out_terminal_dev,
                float* out_q_dev, void* stream) {
   if (n == 0) return C4_OK;
+  C4_ON_STREAM_DEVICE(stream);
   hipLaunchKernelGGL(k_pos_ops, grid_for(n), dim3(256), 0, (hipStream_t)stream, mask_dev, value_dev, col_dev, n, c_ply_penalty,
                      out_mask_dev, out_value_dev, out_legal_dev, out_terminal_dev, out_q_dev);
   HIP_TRY(hipGetLastError());
@@ -1593,6 +1621,7 @@ int c4_pos_ops(const uint64_t* mask_dev, const uint64_t* value_dev, const int32_
 
 int c4_encode_planes(const uint64_t* mask_dev, const uint64_t* value_dev, uint64_t n, uint32_t planes_dtype, void* planes_dev, void* stream) {
   if (n == 0) return C4_OK;
+  C4_ON_STREAM_DEVICE(stream);
   if (planes_dtype == 0)
     hipLaunchKernelGGL(k_encode<float>, grid_for(n * C4_PLANES_LEN), dim3(256), 0, (hipStream_t)stream, mask_dev, value_dev, n, planes_dev);
   else if (planes_dtype == 1)
@@ -1605,6 +1634,7 @@ int c4_encode_planes(const uint64_t* mask_dev, const uint64_t* value_dev, uint64
 
 int c4_expf_logf(const float* x_dev, uint64_t n, int which, float* y_dev, void* stream) {
   if (n == 0) return C4_OK;
+  C4_ON_STREAM_DEVICE(stream);
   hipLaunchKernelGGL(k_expf_logf, grid_for(n), dim3(256), 0, (hipStream_t)stream, x_dev, n, which, y_dev);
   HIP_TRY(hipGetLastError());
   return C4_OK;
@@ -1612,6 +1642,7 @@ int c4_expf_logf(const float* x_dev, uint64_t n, int which, float* y_dev, void* 
 
 int c4_softmax7(const float* logits_dev, const uint32_t* legal_dev, uint64_t n, float* out_dev, uint32_t* out_err_dev, void* stream) {
   if (n == 0) return C4_OK;
+  C4_ON_STREAM_DEVICE(stream);
   hipLaunchKernelGGL(k_softmax7, grid_for(n), dim3(256), 0, (hipStream_t)stream, logits_dev, legal_dev, n, out_dev, out_err_dev);
   HIP_TRY(hipGetLastError());
   return C4_OK;
@@ -1619,6 +1650,7 @@ int c4_softmax7(const float* logits_dev, const uint32_t* legal_dev, uint64_t n, 
 
 int c4_apply_temperature(const float* policy_dev, const float* temperature_dev, uint64_t n, float* out_dev, void* stream) {
   if (n == 0) return C4_OK;
+  C4_ON_STREAM_DEVICE(stream);
   hipLaunchKernelGGL(k_temperature, grid_for(n), dim3(256), 0, (hipStream_t)stream, policy_dev, temperature_dev, n, out_dev);
   HIP_TRY(hipGetLastError());
   return C4_OK;
@@ -1627,6 +1659,7 @@ int c4_apply_temperature(const float* policy_dev, const float* temperature_dev, 
 int c4_dirichlet(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, const uint32_t* legal_dev, float alpha, uint64_t n,
                  float* eta_dev, void* stream) {
   if (n == 0) return C4_OK;
+  C4_ON_STREAM_DEVICE(stream);
   hipLaunchKernelGGL(k_dirichlet, grid_for(n, 64), dim3(64), 0, (hipStream_t)stream, game_id_dev, n_moves_dev, legal_dev, alpha, n, eta_dev);
   HIP_TRY(hipGetLastError());
   return C4_OK;
@@ -1635,6 +1668,7 @@ int c4_dirichlet(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, const
 int c4_sample_move(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, const float* policy_dev, const float* temperature_dev,
                    uint64_t n, int32_t* out_col_dev, uint32_t* out_u32_dev, void* stream) {
   if (n == 0) return C4_OK;
+  C4_ON_STREAM_DEVICE(stream);
   hipLaunchKernelGGL(k_sample_move, grid_for(n), dim3(256), 0, (hipStream_t)stream, game_id_dev, n_moves_dev, policy_dev,
                      temperature_dev, n, out_col_dev, out_u32_dev);
   HIP_TRY(hipGetLastError());

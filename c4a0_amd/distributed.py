@@ -41,41 +41,55 @@ def all_gather_records(local: torch.Tensor, group=None) -> List[torch.Tensor]:
     world = dist.get_world_size(group)
     dev = _collective_device(local, group)
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    return _all_gather_padded(local, counts, group)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n_local, group=group)
+    return _all_gather_padded(local, [int(c) for c in counts.tolist()], group)
 
 
 def _all_gather_padded(local: torch.Tensor, n_per_rank: Sequence[int], group=None) -> List[torch.Tensor]:
+    """One all_gather_into_tensor on a [W, cap, 64] buffer (cap = the largest shard's record count):
+    a single fixed-size collective, no per-rank output copies."""
     world = dist.get_world_size(group)
     dev = _collective_device(local, group)
     cap = max(1, max(n_per_rank))
     padded = torch.zeros((cap, SAMPLE_BYTES), dtype=torch.uint8, device=dev)
     padded[: local.shape[0]] = local.to(dev)
-    bufs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(bufs, padded, group=group)
-    return [b[:c] for b, c in zip(bufs, n_per_rank)]
+    out = torch.empty((world, cap, SAMPLE_BYTES), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out.view(-1), padded.view(-1), group=group)   # flat views: the concatenated form every backend takes
+    return [out[r, :c] for r, c in enumerate(n_per_rank)]
 
 
-def gather_shards(local_records: torch.Tensor, local_counts: np.ndarray, n_games: int, group=None
+class ShardFailed(RuntimeError):
+    """Another rank failed while playing its shard: raised on every rank instead of a hang in the exchange."""
+
+
+def gather_shards(local_records: torch.Tensor, local_counts: np.ndarray, n_games: int, group=None, failed: bool = False
                   ) -> Tuple[List[torch.Tensor], List[np.ndarray]]:
     """The path's one exchange step.  `local_records` uint8[n_r, 64] = this rank's packed records in
     the order of its shard (`shard_indices`), `local_counts` the per-game sample counts of that shard.
     Two fixed-size collectives: the per-game counts (every rank knows the shard sizes, so no size
     exchange), then the records padded to the largest shard's record count (known from the counts).
+    The counts message carries one status word: a rank whose play failed (`failed=True`) still takes
+    part, and EVERY rank then raises `ShardFailed` instead of blocking in the second collective.
     Returns (records per rank, counts per rank) on every rank."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = _collective_device(local_records, group)
     cap_games = max(1, (n_games + world - 1) // world)
-    mine = torch.zeros(cap_games, dtype=torch.int32, device=dev)
-    mine[: len(local_counts)] = torch.as_tensor(np.asarray(local_counts).astype(np.int32), device=dev)
-    all_counts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(all_counts, mine, group=group)
-    counts = [c.cpu().numpy().astype(np.uint32)[: len(shard_indices(n_games, r, world))] for r, c in enumerate(all_counts)]
+    mine = torch.zeros(cap_games + 1, dtype=torch.int32, device=dev)
+    inconsistent = (not failed) and int(np.asarray(local_counts, dtype=np.int64).sum()) != local_records.shape[0]
+    if not failed:
+        mine[: len(local_counts)] = torch.as_tensor(np.asarray(local_counts).astype(np.int32), device=dev)
+    mine[cap_games] = 1 if (failed or inconsistent) else 0
+    all_counts = torch.empty((world, cap_games + 1), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(all_counts.view(-1), mine, group=group)
+    all_counts = all_counts.cpu().numpy()
+    bad = [r for r in range(world) if all_counts[r, cap_games] != 0]
+    if inconsistent:
+        raise ValueError(f"rank {rank}: {local_records.shape[0]} packed records but the counts add up to {int(np.asarray(local_counts, dtype=np.int64).sum())}")
+    if bad:
+        raise ShardFailed(f"self-play failed on rank(s) {bad}; no samples were exchanged")
+    counts = [all_counts[r, : len(shard_indices(n_games, r, world))].astype(np.uint32) for r in range(world)]
     n_per_rank = [int(c.sum()) for c in counts]
-    if n_per_rank[rank] != local_records.shape[0]:
-        raise ValueError(f"rank {rank}: {local_records.shape[0]} packed records but the counts add up to {n_per_rank[rank]}")
     return _all_gather_padded(local_records, n_per_rank, group), counts
 
 
@@ -86,12 +100,6 @@ def merge_shards(per_rank_records: Sequence, per_rank_counts: Sequence[np.ndarra
 
     world = len(per_rank_records)
     return merge_parts(n_games, [(shard_indices(n_games, r, world), per_rank_counts[r], per_rank_records[r]) for r in range(world)])
-
-
-def merge_rank_records(per_rank: Sequence[np.ndarray], n_games: int, world_size: int, counts_per_rank: Sequence[np.ndarray]):
-    """Round-1 name of `merge_shards` (numpy records)."""
-    return merge_shards([per_rank[r] for r in range(world_size)],
-                        [np.asarray(counts_per_rank[r])[: len(shard_indices(n_games, r, world_size))] for r in range(world_size)], n_games)
 
 
 def play_games_sharded(reqs, max_nn_batch_size: int, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float,
@@ -127,15 +135,35 @@ def play_games_sharded(reqs, max_nn_batch_size: int, n_mcts_iterations: int, c_e
     if unknown:
         raise TypeError(f"unknown play_games keywords {sorted(unknown)}")
     kw.update(play_kwargs)
+    if kw["device"] is None:
+        # one process per GPU: LOCAL_RANK (set by torch.distributed.run) names this rank's device; without a
+        # launcher, torch's current device -- never silently cuda:0 for every rank of a multi-GPU node
+        import os
+        lr = os.environ.get("LOCAL_RANK")
+        if lr is not None and int(lr) < torch.cuda.device_count():
+            kw["device"] = torch.device("cuda", int(lr))
+        elif world > 1 and torch.cuda.device_count() > 1:
+            raise ValueError("play_games_sharded: pass device= (or launch with torch.distributed.run, which sets LOCAL_RANK)")
+        else:
+            kw["device"] = torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device(kw["device"])
+    failure = None
+    recs_dev, counts = torch.zeros((0, SAMPLE_BYTES), dtype=torch.uint8, device=dev), np.zeros(0, dtype=np.uint32)   # more ranks than games
     if mine:
-        recs_dev, counts = _play(mine, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, None, evaluator,
-                                 kw["device"], kw["resident_games"], kw["planes_dtype"], kw["blocks_per_slot"], stats, kw["dirichlet"],
-                                 kw["concurrent_sessions"], kw["eval_cache_entries"], on_device=True)
-    else:   # more ranks than games
-        dev = torch.device(kw["device"]) if kw["device"] is not None else torch.device("cuda", torch.cuda.current_device())
-        recs_dev, counts = torch.zeros((0, SAMPLE_BYTES), dtype=torch.uint8, device=dev), np.zeros(0, dtype=np.uint32)
+        try:
+            recs_dev, counts = _play(mine, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, None, evaluator,
+                                     kw["device"], kw["resident_games"], kw["planes_dtype"], kw["blocks_per_slot"], stats, kw["dirichlet"],
+                                     kw["concurrent_sessions"], kw["eval_cache_entries"], on_device=True)
+        except Exception as e:   # the other ranks are about to enter the exchange: tell them, then re-raise here
+            failure = e
+            recs_dev, counts = torch.zeros((0, SAMPLE_BYTES), dtype=torch.uint8, device=dev), np.zeros(0, dtype=np.uint32)
     t0 = time.perf_counter()
-    per_rank, per_counts = gather_shards(recs_dev, counts, n, group)
+    try:
+        per_rank, per_counts = gather_shards(recs_dev, counts, n, group, failed=failure is not None)
+    except ShardFailed:
+        if failure is not None:
+            raise failure
+        raise
     merged, all_counts = merge_shards(per_rank, per_counts, n)          # torch ops on the collective's device
     recs = merged.cpu().numpy().reshape(-1).view(SAMPLE_DTYPE)
     if stats is not None:

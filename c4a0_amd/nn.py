@@ -124,7 +124,7 @@ class InferenceNet:
     graph_safe = True  # forward() is pure device work on caller-owned outputs: may be captured in a HIP graph
 
     def __init__(self, model: ConnectFourNet, device: torch.device, dtype: torch.dtype = torch.bfloat16,
-                 hip_tower: Optional[bool] = None):
+                 hip_tower: Optional[bool] = None, gemm: Optional[str] = None, gemm_config: Optional[int] = None):
         self.device = torch.device(device)
         self.dtype = dtype
         model = model.eval()
@@ -175,6 +175,18 @@ class InferenceNet:
         self.pol_b32 = self.pol_b[-1].to(self.device, torch.float32).contiguous()
         self.val_b32 = self.val_b[-1].to(self.device, torch.float32).contiguous()
         self.fused_epilogue = self.device.type == "cuda" and hasattr(torch, "_addmm_activation")
+        # Hidden layers of the heads: "hip" = the hand-written MFMA GEMM (c4_linear_bf16), whose result for
+        # a position does not depend on the batch or the row it sits in -- the default wherever the HIP
+        # tower runs; "hipblaslt" = PyTorch's library GEMM (kept for A/B timing: its low bits depend on
+        # the batch shape).  C4A0_GEMM / C4A0_GEMM_CONFIG override for experiments.
+        import os
+        gemm = gemm or os.environ.get("C4A0_GEMM") or ("hip" if self.hip_tower else "hipblaslt")
+        if gemm not in ("hip", "hipblaslt"):
+            raise ValueError("gemm must be 'hip' or 'hipblaslt'")
+        if gemm == "hip" and not (self.hip_tower and (42 * self.channels) % 192 == 0):
+            raise ValueError("gemm='hip' needs the HIP tower (bf16, 32 or 64 channels on a HIP device)")
+        self.gemm = gemm
+        self.gemm_config = int(gemm_config if gemm_config is not None else os.environ.get("C4A0_GEMM_CONFIG", "0"))
         mv = lambda ts: [t.to(self.device, dtype).contiguous() for t in ts]
         self.conv_w = [w.to(self.device, dtype).contiguous(memory_format=torch.channels_last) for w in self.conv_w]
         self.conv_b = mv(self.conv_b)
@@ -183,6 +195,10 @@ class InferenceNet:
         if len(self.pol_w) > 1 and len(self.val_w) > 1:
             self.merged_w1 = torch.cat([self.pol_w[0], self.val_w[0]], dim=0).contiguous()
             self.merged_b1 = torch.cat([self.pol_b[0], self.val_b[0]], dim=0).contiguous()
+        self._bias32 = {}   # f32 copies of the hidden layers' biases for the HIP GEMM's epilogue, by bias tensor
+        if self.gemm == "hip":
+            for b in self.pol_b[:-1] + self.val_b[:-1] + ([self.merged_b1] if self.merged_b1 is not None else []):
+                self._bias32[b.data_ptr()] = b.float().contiguous()
 
     @torch.no_grad()
     def tower(self, planes: torch.Tensor) -> torch.Tensor:
@@ -250,7 +266,19 @@ class InferenceNet:
         return lp, q
 
     def _linear_relu(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-        """ReLU(x W^T + b) with the bias and ReLU in the GEMM epilogue (hipBLASLt) where available."""
+        """ReLU(x W^T + b): the hand-written MFMA GEMM, or (gemm="hipblaslt") the library's with the bias
+        and ReLU in its epilogue where available."""
+        if self.gemm == "hip":
+            from ._lib import check
+            import ctypes as C
+
+            assert x.stride(1) == 1 and w.is_contiguous()
+            m, n, k = x.shape[0], w.shape[0], w.shape[1]
+            y = torch.empty((m, n), dtype=torch.bfloat16, device=self.device)
+            check(self._L.c4_linear_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(self._bias32[b.data_ptr()].data_ptr()),
+                                         C.c_void_p(y.data_ptr()), m, n, k, x.stride(0), n, 1, self.gemm_config,
+                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            return y
         if self.fused_epilogue:
             return torch._addmm_activation(b, x, w.t(), use_gelu=False)
         return F.relu(F.linear(x, w, b))

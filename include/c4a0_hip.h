@@ -253,6 +253,16 @@ int c4_sample_move(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, con
 int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w_dev, const float* bias_dev,
                        uint32_t n_boards, uint32_t channels, uint32_t n_blocks, void* out_dev, void* stream);
 
+/* A hidden layer of a head (nn.py:75-100: Linear(F, F) + BatchNorm1d + ReLU, BN folded by the caller):
+ *   y[m][n] = act(sum_k x[m][k] * w[n][k] + bias[n]),  x bf16 [m][ldx], w bf16 [n][k] (nn.Linear's layout),
+ *   bias f32 [n], y bf16 [m][ldy]; relu != 0 applies max(., 0).  Hand-written MFMA kernel whose result for
+ * a row depends on that row and the weights ONLY (one fixed summation order per element whatever m, the row
+ * index or `config`): the evaluator is a function of the position, as the reference's is (one forward per
+ * unique position, self_play.rs:203-237).  n % 192 == 0, k % 64 == 0 (42 * C features, C a multiple of 32);
+ * config 0 = automatic, 1..9 = a specific tile configuration (tools/gemm_probe.py). */
+int c4_linear_bf16(const void* x_dev, const void* w_dev, const float* bias_dev, void* y_dev, uint32_t m, uint32_t n,
+                   uint32_t k, uint32_t ldx, uint32_t ldy, uint32_t relu, uint32_t config, void* stream);
+
 /* Output layers of both heads in one launch (nn.py:84-85,98-99): policy Linear(F->7) + LogSoftmax
  * and value Linear(F->2) + Tanh.  hidden_*_dev bf16 [n_boards][features] with row strides
  * *_row_stride elements (the last hidden activation of each head; they may be two column ranges

@@ -6,6 +6,9 @@
  * Build: see oracle/Makefile (-O2 -ffp-contract=off -mfma: no implicit FMA anywhere;
  * the one explicit fma() below is the one glibc's FMA ifunc variant performs).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   /* pthread_setaffinity_np / CPU_SET for the timing runs' thread pinning */
+#endif
 #include "c4_oracle.h"
 
 #include <math.h>
@@ -1114,6 +1117,13 @@ int c4o_self_play(const c4o_game_metadata* reqs, uint64_t n_games, int max_nn_ba
 #include <sched.h>
 #include <time.h>
 
+/* Timing aid for bench.py's cpu_baseline leg (no effect on any result): with pinning on, the NN thread
+ * (the caller) keeps the first CPU of the process's affinity set to itself and the MCTS workers are
+ * spread one per CPU over the others, so that 15 spinning workers cannot preempt the thread that
+ * feeds them (the source of a +-25 % run-to-run spread). */
+static int g_pin_threads = 0;
+void c4o_set_thread_pinning(int on) { g_pin_threads = on; }
+
 typedef struct {
   uint64_t game;      /* index into games[]; UINT64_MAX = MctsJob::PoisonPill (self_play.rs:317-322) */
   float lp[7], qp, qn;
@@ -1278,6 +1288,22 @@ int c4o_self_play_async(const c4o_game_metadata* reqs, uint64_t n_games, int max
   if (n_games > 0)
     for (; started < a.n_workers; started++)
       if (pthread_create(&th[started], NULL, async_worker, &a) != 0) break;
+  cpu_set_t old_set;
+  int pinned = 0;
+  if (g_pin_threads && started > 0 && sched_getaffinity(0, sizeof old_set, &old_set) == 0 && CPU_COUNT(&old_set) >= 2) {
+    int cpus[CPU_SETSIZE], n_cpus = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++)
+      if (CPU_ISSET(c, &old_set)) cpus[n_cpus++] = c;
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(cpus[0], &one);
+    pinned = pthread_setaffinity_np(pthread_self(), sizeof one, &one) == 0;
+    for (int w = 0; pinned && w < started; w++) {
+      CPU_ZERO(&one);
+      CPU_SET(cpus[1 + w % (n_cpus - 1)], &one);
+      (void)pthread_setaffinity_np(th[w], sizeof one, &one);
+    }
+  }
   int rc = (n_games > 0 && started < a.n_workers) ? C4O_ERR_ILLEGAL_MOVE : C4O_OK;
 
   /* NNThread::loop_until_close (self_play.rs:196-237) on the calling thread */
@@ -1387,6 +1413,7 @@ int c4o_self_play_async(const c4o_game_metadata* reqs, uint64_t n_games, int max
     for (int w = 0; w < started; w++) async_push_jobs(&a, &pill, 1);
   }
   for (int w = 0; w < started; w++) pthread_join(th[w], NULL);
+  if (pinned) (void)pthread_setaffinity_np(pthread_self(), sizeof old_set, &old_set);
 
   uint64_t off = 0;
   for (uint64_t i = 0; i < n_games; i++) {

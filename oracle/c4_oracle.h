@@ -179,6 +179,10 @@ int c4o_self_play_async(const c4o_game_metadata* reqs, uint64_t n_games, int max
                         c4o_eval_fn eval, void* eval_ctx, int n_threads,
                         c4o_sample* out_samples, uint64_t* out_offsets, c4o_selfplay_stats* stats);
 
+/* Timing aid (bench.py cpu_baseline): pin the NN thread to the first CPU of the affinity set and the
+ * workers one per CPU over the rest, for the duration of each c4o_self_play_async call.  No effect on results. */
+void c4o_set_thread_pinning(int on);
+
 /* built-in evaluators usable as c4o_eval_fn (ctx ignored) */
 int c4o_eval_uniform(void* ctx, uint64_t model_id, int n, const float* planes,
                      float* logprobs, float* q_pen, float* q_nopen); /* self_play.rs:391-403: logits=1/7, q=0 */

@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
         "c4o_self_play_async": (C.c_int, [P(GameMetadataC), C.c_uint64, C.c_int, C.c_uint64, C.c_float, C.c_float,
                                           C.c_void_p, C.c_void_p, C.c_int, P(CSample), P(C.c_uint64), P(SelfPlayStats)]),
         "c4o_hash_eval_pos": (None, [C.c_uint64, C.c_uint64, f32p, f32p, f32p]),
+        "c4o_set_thread_pinning": (None, [C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

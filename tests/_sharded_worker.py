@@ -1,10 +1,11 @@
 """Child process of tests/test_gpu_sharded.py: one rank of play_games_sharded on the (shared) GPU.
 
-    python tests/_sharded_worker.py RANK WORLD PORT OUT_DIR N_GAMES N_ITER MODE
+    python tests/_sharded_worker.py RANK WORLD PORT OUT_DIR N_GAMES N_ITER MODE [BACKEND]
 
 Started as a fresh process (nothing here runs before the interpreter starts: no GPU state is
-inherited), backend gloo: the records are staged through the host, everything else is the product
-path (real sessions, device packing, both collectives, the merge)."""
+inherited).  BACKEND gloo (default): the records are staged through the host, everything else is the
+product path (real sessions, device packing, both collectives, the merge).  BACKEND nccl = RCCL, the
+backend of the real 8-GPU job; one rank per device (so world size 1 on a one-GPU box)."""
 import os
 import pickle
 import sys
@@ -15,6 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, out_dir, n_games, n_iter, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+    backend = sys.argv[8] if len(sys.argv) > 8 else "gloo"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     import torch
@@ -24,14 +26,21 @@ def main():
     from c4a0_amd.distributed import play_games_sharded
     from tests.helpers import GraphSafeHashEval, hash_eval_torch
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dev_index = rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        device = f"cuda:{dev_index}"
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        device = "cuda:0"
     reqs = [GameMetadata(1000 + 7 * i, 0, 0) for i in range(n_games)]
     stats = {}
     if mode == "graph2":     # HIP-graph replay, two concurrent sessions per rank
-        res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, evaluator=GraphSafeHashEval(), device="cuda:0",
+        res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, evaluator=GraphSafeHashEval(), device=device,
                                  resident_games=16, concurrent_sessions=2, stats=stats)
     else:                    # eager single session per rank, slots refilled from the rank's queue
-        res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, evaluator=hash_eval_torch, device="cuda:0",
+        res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, evaluator=hash_eval_torch, device=device,
                                  resident_games=8, stats=stats)
     with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
         pickle.dump({"cbor": res.to_cbor(), "allgather": stats["sample_allgather"], "games_done": stats.get("games_done")}, f)

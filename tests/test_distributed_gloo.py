@@ -75,6 +75,38 @@ def test_two_rank_shard_and_allgather(tmp_path, n_games):
         assert got.tobytes() == want_recs.tobytes()
 
 
+def _failing_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from c4a0_amd.distributed import ShardFailed, gather_shards
+
+    n_games = 6
+    recs, counts = _records_for([100 + rank + world * i for i in range(3)])
+    local = torch.from_numpy(recs.view(np.uint8).reshape(-1, 64).copy())
+    try:
+        if rank == 1:   # this rank's play "failed": it still joins the counts exchange, flagged
+            gather_shards(torch.zeros((0, 64), dtype=torch.uint8), np.zeros(0, dtype=np.uint32), n_games, failed=True)
+        else:
+            gather_shards(local, counts, n_games)
+        outcome = "returned"
+    except ShardFailed as e:
+        outcome = f"ShardFailed: {e}"
+    open(os.path.join(out_dir, f"outcome_{rank}.txt"), "w").write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failed_rank_makes_every_rank_raise_instead_of_hanging(tmp_path):
+    """without agreement a rank that raised in _play left the others blocked in all_gather."""
+    world, port = 2, _free_port()
+    mp.spawn(_failing_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        out = open(tmp_path / f"outcome_{rank}.txt").read()
+        assert out.startswith("ShardFailed") and "[1]" in out, out
+
+
 def test_shard_indices_partition():
     from c4a0_amd.distributed import shard_indices
 

@@ -302,14 +302,18 @@ def test_play_games_narrows_the_tail_without_changing_samples():
 
 
 def test_search_width_beyond_the_arena_limit_is_refused_with_a_reason():
-    """n_mcts_iterations > 2048 cannot be guaranteed a large enough arena (16-bit child
-    links): the session refuses it at creation instead of failing in the middle of a job."""
+    """beyond n_mcts_iterations = 1523 the provable worst case (43 n + 8 blocks per game)
+    no longer fits the 16-bit child links: the session refuses the default sizing at creation instead
+    of failing in the middle of a job; the widest provable search and an explicit arena are accepted."""
     from c4a0_amd._lib import C4Error
     from c4a0_amd.session import DeviceSession
 
-    with pytest.raises(C4Error, match="n_mcts_iterations > 2048"):
-        DeviceSession(2, 3000, 6.6, 0.01)
-    s = DeviceSession(2, 2000, 6.6, 0.01)     # capped arena, still accepted
+    for n in (3000, 2000, 1524):
+        with pytest.raises(C4Error, match="n_mcts_iterations > 1523"):
+            DeviceSession(2, n, 6.6, 0.01)
+    s = DeviceSession(2, 1523, 6.6, 0.01)                        # 43 * 1523 + 8 = 65497 blocks
+    s.close()
+    s = DeviceSession(2, 2000, 6.6, 0.01, blocks_per_slot=65535)  # the caller's own risk, stated in the message
     s.close()
 
 
