@@ -26,6 +26,7 @@
 //     holds half of a layer's weights (144 registers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <string>
 
@@ -330,6 +331,20 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   c4host::DeviceGuard guard(device);
   if (guard.error() != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: hipSetDevice: ") + hipGetErrorString(guard.error()));
   TowerParams p{(const uint16_t*)planes_dev, (const bf16x8*)w0_dev, (const bf16x8*)w_dev, bias_dev, (uint16_t*)out_dev, n_boards, n_blocks};
+  // experiment knob (tools/tower_probe.py): other wavefront counts / tiles in flight for the 32-channel tower
+  static const int variant = [] { const char* e = getenv("C4_TOWER_VARIANT"); return e ? atoi(e) : 0; }();
+  if (channels == 32 && variant) {
+    switch (variant) {
+      case 1: return launch_tower<32, 16, 768, 2, 1>(p, n_boards, (hipStream_t)stream, device);    // 12 wavefronts, 4 tiles each
+      case 2: return launch_tower<32, 16, 1024, 1, 1>(p, n_boards, (hipStream_t)stream, device);   // 16 wavefronts, 3 tiles each, one in flight
+      case 3: return launch_tower<32, 16, 512, 3, 1>(p, n_boards, (hipStream_t)stream, device);    // 8 wavefronts, three tiles in flight
+      case 4: return launch_tower<32, 16, 512, 1, 1>(p, n_boards, (hipStream_t)stream, device);    // 8 wavefronts, one tile in flight
+      case 5: return launch_tower<32, 16, 768, 1, 1>(p, n_boards, (hipStream_t)stream, device);    // 12 wavefronts, one tile in flight
+      case 6: return launch_tower<32, 16, 768, 4, 1>(p, n_boards, (hipStream_t)stream, device);    // 12 wavefronts, all four tiles in flight
+      case 7: return launch_tower<32, 8, 512, 3, 1>(p, n_boards, (hipStream_t)stream, device);     // the small-launch variant
+      default: break;
+    }
+  }
   if (channels == 32 && n_boards <= 8 * 160)
     // small launches (up to 1 280 boards): 8 boards per workgroup, three tiles in flight per wave, so
     // that the launch spreads over twice as many CUs (2 048 boards alone: 31.6 -> 20.5 us).  NOT used for

@@ -19,9 +19,11 @@
 // 16-byte slot of k-group g of row r lives at slot g ^ (r & 7) (the XOR goes on the per-lane SOURCE
 // address, the LDS image stays lane-linear), which makes every ds_read_b128 of a fragment bank-conflict
 // free.  One raw s_barrier per k-tile, counted vmcnt waits: loads stay in flight across barriers.
-// The default configuration keeps a workgroup at 4 wavefronts / 80 KB so that TWO share a CU: one's
-// prologue, barriers and epilogue run under the other's MFMAs (the kernels of the other session's
-// stream are what usually sits beside it).
+// The DMA pieces of a k-tile are issued one or two at a time BETWEEN the MFMA groups of an earlier k-tile
+// (never as a burst in front of them), fragment reads are software-pipelined across the two 32-deep
+// halves of a k-tile, and hipcc's counted lgkmcnt waits let MFMAs start on the first fragments.
+// Default: 128 x 192 tile, 8 wavefronts (64 x 48 each), 3-deep ring (120 KB) -- chosen in the bench, see
+// c4_linear_bf16 below; the other configurations are kept as measured alternatives (same bits).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -108,14 +110,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmPa
   // counts on vmcnt only, so the fragment reads below get counted lgkmcnt waits.)
   const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.M * p.ldx * 2u), 0x00020000);
   const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(p.N * p.K * 2u), 0x00020000);
-  auto issue = [&](int kt) __attribute__((always_inline)) {
+  auto issue_one = [&](int kt, int i) __attribute__((always_inline)) {
     uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
+    const int c = wave + kWaves * i;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((c < BM / 8) ? x_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)(st + c * 1024), 16,
+                                             (int)src_off[i], kt * (BK * 2), 0, 0);
+  };
+  auto issue = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < L; i++) {
-      const int c = wave + kWaves * i;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds((c < BM / 8) ? x_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)(st + c * 1024), 16,
-                                               (int)src_off[i], kt * (BK * 2), 0, 0);
-    }
+    for (int i = 0; i < L; i++) issue_one(kt, i);
   };
 
   f32x4 acc[TN][TM];
@@ -136,14 +139,20 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmPa
     if (s < KT) issue(s);
 
   for (int kt = 0; kt < KT; kt++) {
-    // k-tile kt must have landed; up to NSTAGE - 2 younger ones may stay in flight
-    const int rem = KT - 1 - kt;
-    const int younger = rem < NSTAGE - 2 ? rem : NSTAGE - 2;
-    if (NSTAGE >= 4 && younger == 2) wait_vmcnt<2 * L>();
-    else if (NSTAGE >= 3 && younger == 1) wait_vmcnt<L>();
-    else wait_vmcnt<0>();
+    // k-tile kt must have landed; the NSTAGE - 2 younger ones stay in flight.  (Pieces are issued for
+    // every kt, also past the last k-tile -- into a stage nobody reads again, within the operands'
+    // buffer bounds -- so the count of outstanding pieces is the same in every iteration: no branch
+    // around an issue, no tail cases in the wait.)
+    wait_vmcnt<(NSTAGE - 2) * L>();
     __builtin_amdgcn_s_barrier();                               // everybody's pieces of kt landed; everybody left buffer (kt - 1) % NSTAGE
-    if (kt + NSTAGE - 1 < KT) issue(kt + NSTAGE - 1);
+    // The DMA pieces of k-tile kt + NSTAGE - 1 are NOT issued here in one burst (a wavefront would spend
+    // hundreds of cycles queueing 1 KB requests before its first MFMA): they are handed out between the
+    // MFMA groups below, one or two at a time, so the address pipe works under the matrix pipe.  With two
+    // stages they all go out in the first half of the k-tile (the second half gives them time to land),
+    // with three or more over the whole k-tile.
+    const int lkt = kt + NSTAGE - 1;
+    constexpr int kLoadSteps = NSTAGE == 2 ? TN : 2 * TN;
+    constexpr int kLoadsPerStep = (L + kLoadSteps - 1) / kLoadSteps;
     const uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
     // Fragment reads of the first 32-deep half are requested up front (activations first: the first
     // MFMAs need all TM of them and one weight fragment); the second half's reads are issued between
@@ -170,15 +179,23 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmPa
       for (int r = a * kPerStep; r < (a + 1) * kPerStep && r < TN + TM; r++) {
         if (r < TM) rd_x(1, r); else rd_w(1, r - TM);
       }
+#pragma unroll
+      for (int j = a * kLoadsPerStep; j < (a + 1) * kLoadsPerStep && j < L; j++) issue_one(lkt, j);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int a = 0; a < TN; a++)
+    for (int a = 0; a < TN; a++) {
 #pragma unroll
       for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+      if (NSTAGE >= 3) {
+#pragma unroll
+        for (int j = (TN + a) * kLoadsPerStep; j < (TN + a + 1) * kLoadsPerStep && j < L; j++) issue_one(lkt, j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
+  wait_vmcnt<0>();   // the pieces issued past the last k-tile must not land in an LDS allocation that was given away
   // ---- epilogue: lane holds features n0 + 4 lg + {0..3} of board m (C/D map: row = 4 (lane >> 4) + reg, col = lane & 15)
 #pragma unroll
   for (int a = 0; a < TN; a++) {
@@ -239,7 +256,14 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
   if (guard.error() != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16: hipSetDevice: ") + hipGetErrorString(guard.error()));
   GemmParams p{(const uint16_t*)x_dev, (const uint16_t*)w_dev, bias_dev, (uint16_t*)y_dev, m, n, k, ldx, ldy, relu, 0, 0, 0, 0};
   hipStream_t st = (hipStream_t)stream;
-  if (config == 0) config = m <= 512 ? 9 : 1;
+  // Automatic choice, measured on MI355X IN THE BENCH (two sessions' kernels sharing the chip), not alone
+  // (profiles/r03_gemm_configs.txt; every configuration gives the same bits): the 128 x 192 tile with
+  // 8 wavefronts and a 3-deep ring wins for the wide AND the narrow layers -- it pulls the fewest operand
+  // bytes out of L2 per flop of all tiles that still give every layer >= 112 workgroups, and the CUs its
+  // narrow-layer launches leave free go to the other session's kernels.  Finer tilings that look better
+  // alone (128 x 96: 13.5 vs 16.6 us for a 2048 x 1344 x 1344 layer) lose 8-13 % of games/s in the mix.
+  // Small batches (callback mode, tails) want many small tiles: latency, not CU-time.
+  if (config == 0) config = m <= 1024 ? 10 : 11;
   switch (config) {
     case 1: return launch_gemm<128, 192, 2, 2, 2, 2>(p, st, device);   // 4 wavefronts (64 x 96 each), 80 KB: two workgroups per CU
     case 2: return launch_gemm<128, 192, 2, 4, 4, 1>(p, st, device);   // 8 wavefronts (64 x 48), 4-deep ring, the whole LDS
@@ -250,6 +274,13 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     case 7: return launch_gemm<256, 192, 4, 2, 2, 1>(p, st, device);   // 8 wavefronts (64 x 96), 112 KB
     case 8: return launch_gemm<128, 96, 2, 2, 4, 1>(p, st, device);    // 4 wavefronts (64 x 48), 4-deep ring, 112 KB
     case 9: return launch_gemm<64, 96, 2, 2, 4, 2>(p, st, device);     // 4 wavefronts (32 x 48), 80 KB: small batches
+    case 10: return launch_gemm<128, 96, 2, 2, 3, 1>(p, st, device);   // 4 wavefronts (64 x 48), 3-deep ring, 84 KB
+    case 11: return launch_gemm<128, 192, 2, 4, 3, 1>(p, st, device);  // 8 wavefronts (64 x 48), 3-deep ring, 120 KB
+    case 12: return launch_gemm<128, 192, 1, 4, 3, 1>(p, st, device);  // 4 wavefronts (128 x 48), 3-deep ring, 120 KB
+    case 13: return launch_gemm<128, 192, 2, 2, 4, 1>(p, st, device);  // 4 wavefronts (64 x 96), 4-deep ring, 160 KB
+    case 14: return launch_gemm<256, 96, 2, 2, 3, 1>(p, st, device);   // 4 wavefronts (128 x 48), 3-deep ring, 132 KB
+    case 15: return launch_gemm<64, 192, 1, 4, 3, 1>(p, st, device);   // 4 wavefronts (64 x 48), 3-deep ring, 96 KB
+    case 16: return launch_gemm<64, 192, 2, 4, 3, 1>(p, st, device);   // 8 wavefronts (32 x 48), 3-deep ring, 96 KB
     default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
   }
 }

@@ -186,7 +186,9 @@ class InferenceNet:
         if gemm == "hip" and not (self.hip_tower and (42 * self.channels) % 192 == 0):
             raise ValueError("gemm='hip' needs the HIP tower (bf16, 32 or 64 channels on a HIP device)")
         self.gemm = gemm
-        self.gemm_config = int(gemm_config if gemm_config is not None else os.environ.get("C4A0_GEMM_CONFIG", "0"))
+        # tile configuration: one number, or "wide,narrow" (the merged 2F-wide first layer, the F-wide layers); 0 = automatic
+        cfg = str(gemm_config if gemm_config is not None else os.environ.get("C4A0_GEMM_CONFIG", "0")).split(",")
+        self.gemm_config = (int(cfg[0]), int(cfg[-1]))
         mv = lambda ts: [t.to(self.device, dtype).contiguous() for t in ts]
         self.conv_w = [w.to(self.device, dtype).contiguous(memory_format=torch.channels_last) for w in self.conv_w]
         self.conv_b = mv(self.conv_b)
@@ -276,7 +278,7 @@ class InferenceNet:
             m, n, k = x.shape[0], w.shape[0], w.shape[1]
             y = torch.empty((m, n), dtype=torch.bfloat16, device=self.device)
             check(self._L.c4_linear_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(self._bias32[b.data_ptr()].data_ptr()),
-                                         C.c_void_p(y.data_ptr()), m, n, k, x.stride(0), n, 1, self.gemm_config,
+                                         C.c_void_p(y.data_ptr()), m, n, k, x.stride(0), n, 1, self.gemm_config[0 if n > k else 1],
                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             return y
         if self.fused_epilogue:

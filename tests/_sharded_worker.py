@@ -36,7 +36,12 @@ def main():
         device = "cuda:0"
     reqs = [GameMetadata(1000 + 7 * i, 0, 0) for i in range(n_games)]
     stats = {}
-    if mode == "graph2":     # HIP-graph replay, two concurrent sessions per rank
+    if mode == "net":        # the real bf16 4-block / 32-channel network (same weights on every rank: same seed)
+        from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+        torch.manual_seed(1337)
+        net = InferenceNet(ConnectFourNet(ModelConfig(4, 32, 4, 2)), torch.device(device), dtype=torch.bfloat16)
+        res = play_games_sharded(reqs, 4096, n_iter, 6.6, 0.01, evaluator=net, device=device, resident_games=256, stats=stats)
+    elif mode == "graph2":     # HIP-graph replay, two concurrent sessions per rank
         res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, evaluator=GraphSafeHashEval(), device=device,
                                  resident_games=16, concurrent_sessions=2, stats=stats)
     else:                    # eager single session per rank, slots refilled from the rank's queue

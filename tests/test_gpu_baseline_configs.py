@@ -61,11 +61,21 @@ def _oracle_replay(seq_by_slot, slot_ids, n_iter, dirichlet=(0.0, 0.0)):
     """T3: the oracle plays each logged game ALONE and is answered, leaf by leaf, with
     what the device's evaluator said for that game's row at that step.  The k-th non-terminal leaf
     the oracle asks about must BE the k-th leaf the device showed its evaluator (checked), so the
-    whole search sequence is compared, not only the samples.  Keyed by the game's own sequence and
-    not by position: a library GEMM's low bits may depend on the row a position sits in.
+    whole search sequence is compared, not only the samples -- and every logged position must have been
+    answered with the same bits wherever and whenever it was shown (the evaluator is a function of the
+    position; round 2's library GEMMs were not).
     seq_by_slot[slot] as returned by _run_logged; slot_ids = [(slot, game id)]."""
     from oracle import c4oracle as O
     from tests.helpers import oracle_samples_by_game, planes_to_pos_np
+
+    # The evaluator is a FUNCTION OF THE POSITION (round 3: hand-written GEMMs with one fixed summation
+    # order per element): whichever slot, row or step showed a position, the answer has the same bits.
+    # (Not with Dirichlet noise off/on: noise does not touch the evaluator.)  Checked over every logged row.
+    table = {}
+    for seq in seq_by_slot.values():
+        for pos, a, b in seq:
+            if table.setdefault(pos, (a, b)) != (a, b):
+                raise AssertionError(f"the evaluator answered position {pos} with different bits in different rows / steps")
 
     out = {}
     for slot, gid in slot_ids:

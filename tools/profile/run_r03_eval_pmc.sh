@@ -12,7 +12,10 @@ PASSES=(
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
  "FETCH_SIZE"
  "WRITE_SIZE"
- "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_CYCLES_sum"
+ "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_TA_BUSY_sum"
+ "SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_LDS SQ_INSTS_LDS_LOAD SQ_INSTS_VMEM"
+ "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCR_TCP_STALL_CYCLES_sum TD_TD_BUSY_sum"
+ "TCC_BUSY_avr TCC_REQ_sum"
 )
 for BK in "hip 0" "hipblaslt 0" ${EXTRA_BACKENDS}; do
   set -- $BK; B=$1; C=$2
