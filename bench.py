@@ -9,7 +9,7 @@ positions (HIP-graph replay, bf16) and the fused HIP step kernel consumes the ou
 backup, move/finish/refill, select, encode the next leaves; a game whose new leaf is terminal
 runs that simulation in the same launch).  The G games are split over two sessions whose graphs
 replay concurrently on two streams (--sessions); a round advances both.  One bench "step" = R
-rounds (--rounds-per-step, R = 704 = 22 replays of the 32-round graph; `config.rounds_per_step`):
+rounds (--rounds-per-step, R = 704 = 11 replays of the 64-round graph; `config.rounds_per_step`):
 the hot path over one batch of work large enough that `--steps 20` completes >= 10 x 4 096 games
 inside the timed region.  Workload at every N:
 BASELINE config 2 per GPU -- 4 096 concurrent games, n_mcts_iterations = 100, 4-block/32-channel
@@ -239,7 +239,7 @@ def main():
                     help="timed steps of --rounds-per-step lock-step rounds each; 20 x 704 rounds complete >= 10 x 4096 games (SURVEY 8d, C2)")
     ap.add_argument("--warmup", type=int, default=1, help="untimed steps after the pre-roll")
     ap.add_argument("--rounds-per-step", type=int, default=704,
-                    help="lock-step rounds (one MCTS simulation per resident game) per bench step; 704 = 22 replays of the 32-round HIP graph")
+                    help="lock-step rounds (one MCTS simulation per resident game) per bench step; 704 = 11 replays of the 64-round HIP graph")
     ap.add_argument("--games-per-gpu", type=int, default=4096, help="resident games per GPU (BASELINE config 2: 4096)")
     ap.add_argument("--n-mcts", type=int, default=100)
     ap.add_argument("--blocks", type=int, default=4, help="residual blocks")
@@ -248,7 +248,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--eager", action="store_true", help="no HIP graph: launch every kernel from the host")
-    ap.add_argument("--steps-per-graph", type=int, default=32, help="lock-step rounds per HIP-graph replay (measured: 8 -> 23.9 k, 32 -> 24.5 k, 128 -> 23.8 k games/s)")
+    ap.add_argument("--steps-per-graph", type=int, default=64, help="lock-step rounds per HIP-graph replay (paired graph, round 3: 16 -> 24.8 k, 32 -> 25.2 k, 64 -> 25.5 k games/s)")
     ap.add_argument("--one-sim-per-step", action="store_true",
                     help="A/B knob: C4_FLAG_ONE_SIM_PER_STEP (no same-launch simulation for terminal leaves)")
     ap.add_argument("--instrumented-steps", type=int, default=320, help="event-bracketed step-kernel launches for the roofline object (>= 300 whatever --steps is)")
@@ -259,6 +259,9 @@ def main():
     ap.add_argument("--sessions", type=int, default=2,
                     help="the resident games are split over this many sessions that replay their HIP graphs "
                          "concurrently on separate streams (1 = one session, one stream)")
+    ap.add_argument("--independent-graphs", action="store_true",
+                    help="A/B knob: two sessions replay two independent graphs (round 1-2) instead of ONE graph that pipelines them "
+                         "explicitly (session.capture_pair)")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="internal: compute the cpu_baseline object alone and print it (the bench runs this leg in a child "
                          "process under a time limit, so that the checker can never cost the GPU line)")
@@ -314,6 +317,7 @@ def main():
     ids = [rank + world * i for i in range(n_games)]
     sessions, streams, graphs, graphs1 = [], [], [], []   # graphs1: one round per replay, for the K % U remainder
     U = 1 if args.eager else max(1, args.steps_per_graph)
+    paired = P == 2 and not args.eager and not args.independent_graphs
     for p in range(P):
         sp = DeviceSession((G + P - 1 - p) // P, n_iter, 6.6, 0.01, device=device, planes_dtype=torch.bfloat16,
                            one_sim_per_step=args.one_sim_per_step)
@@ -329,11 +333,16 @@ def main():
             sp.set_timing(False)
             graphs.append(None)
             graphs1.append(None)
-        else:
+        elif not paired:
             graphs.append(sp.capture_steps(net, U, stream=st if P > 1 else None))
             graphs1.append(sp.capture_steps(net, 1, stream=st if P > 1 else None) if U > 1 else graphs[-1])
         sessions.append(sp)
         streams.append(st)
+    pair_graph = pair_graph1 = None
+    if paired:   # both sessions' rounds in ONE graph, explicitly pipelined against each other (session.capture_pair)
+        from c4a0_amd.session import capture_pair
+        pair_graph = capture_pair(sessions, streams, net, U)
+        pair_graph1 = capture_pair(sessions, streams, net, 1) if U > 1 else pair_graph
 
     # RCCL comes up only now, AFTER the HIP graphs are captured: its watchdog thread must not poll
     # events while a stream capture is open
@@ -358,6 +367,13 @@ def main():
 
     def run_steps(k):
         """k lock-step rounds of every session: HIP-graph replays of U rounds each, remainder launched eagerly."""
+        if paired:
+            with torch.cuda.stream(streams[0]):
+                for _ in range(k // U):
+                    pair_graph.replay()
+                for _ in range(k % U):
+                    pair_graph1.replay()
+            return
         for _ in range(k // U if graphs[0] is not None else 0):
             for st, g in zip(streams, graphs):
                 with torch.cuda.stream(st):
@@ -495,7 +511,8 @@ def main():
                                    f"{cfg.n_residual_blocks}-block/{cfg.conv_filter_size}-ch ResNet bf16, c_exploration=6.6, c_ply_penalty=0.01",
                        "rounds_per_step": R, "step": f"{R} lock-step rounds (one MCTS simulation per resident game each)",
                        "games_per_gpu": G, "n_mcts_iterations": n_iter, "parallelism": f"games sharded id%{world}",
-                       "evaluator": "eager" if args.eager else f"hip-graph x{U} steps (evaluator + step kernel)",
+                       "evaluator": "eager" if args.eager else (f"one hip-graph x{U} rounds of both sessions, explicitly pipelined (session.capture_pair)" if paired
+                                                                else f"hip-graph x{U} steps (evaluator + step kernel)"),
                        "concurrent_sessions": P, "games_per_session": [sp.n_slots for sp in sessions], "preroll_steps": preroll,
                        "eval_cache_entries_per_session": args.eval_cache,
                        "tree_dtype": "u64 bitboards + f32 UCT"},

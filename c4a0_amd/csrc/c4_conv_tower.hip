@@ -20,10 +20,10 @@
 //     (two board rows): 16 distinct 16-byte slots per channel group -> bank-conflict free.
 //   * D leaves the MFMA as 4 consecutive output channels per lane for one cell: bias, ReLU and
 //     the residual add happen in registers and go back to LDS as one 8-byte store.
-//   * 8 waves per workgroup (two per SIMD).  C = 32: each owns 1/8 of the tiles of every layer, two
-//     tiles in flight per wave so consecutive MFMAs never wait on their accumulator.  C = 64: the
-//     waves work in pairs that share 1/4 of the tiles and split the output channels, so a wave
-//     holds half of a layer's weights (144 registers).
+//   * 8 waves per workgroup (two per SIMD).  C = 32: each owns 1/8 of the tiles of every layer and walks
+//     them software-pipelined (next tile's fragments and the previous tile's epilogue under the
+//     current tile's MFMAs, see tower_layer).  C = 64: the waves work in pairs that share 1/4 of the
+//     tiles and split the output channels, so a wave holds half of a layer's weights (144 registers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -78,25 +78,30 @@ struct TowerParams {
   uint32_t n_blocks;
 };
 
-// One conv layer for this wavefront's tiles.  kConv0: the 2-channel input layer (3 k-steps whose
-// k-groups are taps); otherwise a C -> C layer (9 taps x C/32 k-steps).
+// One conv layer for this wavefront's G cell tiles.  kConv0: the 2-channel input layer (3 k-steps whose
+// k-groups are taps); otherwise a C -> C layer (9 taps x C/32 k-steps).  kSecond: the second conv of a
+// residual block (dst += ReLU(.)).
 //
-// Schedule per wavefront:
-//   * a "pair" = TPP tiles in flight = TPP x MT independent accumulators, started at the bias;
-//   * all B fragments of a pair are requested from LDS up front; counted waits let the MFMAs start
-//     as they arrive.  At C = 32 the workgroup runs 8 wavefronts (two per SIMD), so one wavefront's
-//     LDS waits and epilogue overlap the other's MFMAs (measured: better than software-pipelining
-//     a single wavefront per SIMD);
+// Schedule per wavefront (round 3; the round-2 kernel read 18 fragments, waited for ALL of them and for
+// the weight DMA, ran 36 MFMAs back to back and then a serial epilogue of four dependent LDS round
+// trips: the matrix pipe was busy 43 % of the time, profiles/r03_evaluator_pmc.json):
+//   * one tile (MTW accumulators, started at the bias) per step, software-pipelined over the tiles:
+//     while tile g's MFMAs run, tile g + 1's B fragments are already on their way from LDS (kPrefetch:
+//     a second fragment set, C = 32) and the epilogue of tile g - 1 -- bias/ReLU/residual/convert and
+//     its 8-byte LDS stores -- is issued between them by the scheduler (same basic block, no branch:
+//     the residual was read a step earlier, halo lanes are masked at the store only);
+//   * counted lgkmcnt waits: an MFMA waits for the fragments it uses, not for everything in flight (the
+//     weight staging uses the MUBUF form of LDS-DMA: with the flat-encoded global_load_lds hipcc drains
+//     vmcnt AND lgkmcnt to zero in front of the first MFMA of every tile);
 //   * weights: C = 32 -- the workgroup fetches each layer's 18 KB ONCE, by global->LDS DMA into one of
-//     two stages a whole layer ahead, and every wavefront copies them LDS->registers at the start
-//     of the layer (eight wavefronts each pulling the same 18 KB through the vector L1 cost ~1 us
-//     per layer).  C = 64 -- requested from global memory after this layer's last epilogue.
-template <int C, int NB, bool kConv0, int TPP, int MTW, typename WF, typename Hook>
+//     two stages a whole layer ahead, and every wavefront copies them LDS->registers at the start of
+//     the layer.  C = 64 -- requested from global memory after this layer's last epilogue.
+template <int C, int NB, bool kConv0, bool kSecond, int G_TILES, int MTW, bool kPrefetch, typename WF, typename Hook>
 __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4* __restrict__ dst, WF& wf,
-                                            const float* __restrict__ bias, bool is_second, int tile_lo, int tile_hi,
-                                            int m0, int lane, Hook&& after_last_pair) {
+                                            const float* __restrict__ bias, int tile_lo, int m0, int lane, Hook&& after_last_tile) {
   using G = Geo<C, NB>;
   constexpr int kSteps = kConv0 ? 3 : 9 * G::KC;        // MFMA k-steps (= B fragments) per tile
+  constexpr int NF = kPrefetch ? 2 : 1;                 // fragment sets
   const int li = lane & 15, lg = lane >> 4;
 
   f32x4 bias4[MTW];   // this wavefront's output-channel tiles are m0 .. m0 + MTW - 1
@@ -106,21 +111,21 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
     bias4[m] = f32x4{bp[0], bp[1], bp[2], bp[3]};
   }
 
-  struct Pair {
-    f32x4 acc[TPP][MTW];
-    int bidx[TPP], slot[TPP];
-    int n_live;          // tiles of this group that exist (the last group of a wavefront may be short)
+  uint4 fr[NF][kSteps];
+  f32x4 acc[2][MTW];
+  uint2 old[2][MTW];
+  int e_slot[2], e_cell[2];     // of the tile whose accumulators sit in acc[.]: 16-byte slot index in a plane, padded cell
+
+  auto tile_cell = [&](int g, int& cell) __attribute__((always_inline)) {   // plane-relative slot of this lane's cell of tile g
+    const int tl = tile_lo + g;
+    const int bidx = tl / kTilesPerBoard;
+    const int slot = 9 + 16 * (tl - bidx * kTilesPerBoard) + li;            // cell_slot of the tile's first cell is 9 + 16 j
+    cell = slot;
+    return bidx * kBS + slot;
   };
-  auto geom = [&](int tile, Pair& pr) __attribute__((always_inline)) {
-    pr.n_live = tile_hi - tile < TPP ? tile_hi - tile : TPP;
-#pragma unroll
-    for (int u = 0; u < TPP; u++) {
-      const int tl = u < pr.n_live ? tile + u : tile;   // a missing tile recomputes the first one (never stored)
-      pr.bidx[u] = tl / kTilesPerBoard;
-      pr.slot[u] = 9 + 16 * (tl - pr.bidx[u] * kTilesPerBoard) + li;   // cell_slot of the tile's first cell is 9 + 16 j
-    }
-  };
-  auto load_frags = [&](const Pair& pr, uint4 (&fr)[TPP][kSteps]) __attribute__((always_inline)) {
+  auto load_frags = [&](int g, int f) __attribute__((always_inline)) {
+    int cell;
+    const int base = tile_cell(g, cell);
 #pragma unroll
     for (int k = 0; k < kSteps; k++) {
       int d, plane;
@@ -136,64 +141,85 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
         d = 8 * (t / 3 - 1) + (t % 3 - 1);
         plane = 4 * kc + lg;
       }
-#pragma unroll
-      for (int u = 0; u < TPP; u++) fr[u][k] = src[plane * G::kPlane + pr.bidx[u] * kBS + pr.slot[u] + d];
+      fr[f][k] = src[plane * G::kPlane + base + d];
     }
   };
-  auto mfmas = [&](Pair& pr, const uint4 (&fr)[TPP][kSteps]) __attribute__((always_inline)) {
+  // 8-byte half of the 16-byte slot of channel group 2 (m0 + m) + lg / 2 for this lane's cell
+  auto out_ptr = [&](int slot_in_plane, int m) __attribute__((always_inline)) {
+    return reinterpret_cast<uint2*>(&dst[(2 * (m0 + m) + (lg >> 1)) * G::kPlane + slot_in_plane]) + (lg & 1);
+  };
+  auto start_tile = [&](int g, int a) __attribute__((always_inline)) {     // geometry + residual of tile g, accumulators at the bias
+    e_slot[a] = tile_cell(g, e_cell[a]);
 #pragma unroll
-    for (int u = 0; u < TPP; u++)
-#pragma unroll
-      for (int m = 0; m < MTW; m++) pr.acc[u][m] = bias4[m];
+    for (int m = 0; m < MTW; m++) {
+      acc[a][m] = bias4[m];
+      if (kSecond && kPrefetch) old[a][m] = *out_ptr(e_slot[a], m);   // read now, used one step later: only this lane ever rewrites these bytes
+    }
+  };
+  auto mfmas = [&](int f, int a) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < kSteps; k++)
 #pragma unroll
-      for (int u = 0; u < TPP; u++)
-#pragma unroll
-        for (int m = 0; m < MTW; m++)
-          pr.acc[u][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k][m], __builtin_bit_cast(bf16x8, fr[u][k]), pr.acc[u][m], 0, 0, 0);
+      for (int m = 0; m < MTW; m++)
+        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k][m], __builtin_bit_cast(bf16x8, fr[f][k]), acc[a][m], 0, 0, 0);
   };
-  // lane holds output channels 16 m + 4 lg + {0..3} of cell `slot`
-  auto epilogue = [&](const Pair& pr) __attribute__((always_inline)) {
+  // lane holds output channels 16 m + 4 lg + {0..3} of its cell
+  auto epilogue = [&](int a) __attribute__((always_inline)) {
+    const bool valid = ((e_cell[a] - 1) & 7) != 0;       // padded column 0 is halo: computed, never stored
 #pragma unroll
-    for (int u = 0; u < TPP; u++) {
-      const bool valid = (((pr.slot[u] - 1) & 7) != 0) && u < pr.n_live;   // padded column 0 is halo
-      if (valid) {
-#pragma unroll
-        for (int m = 0; m < MTW; m++) {
-          f32x4 v = pr.acc[u][m];
-          // 8-byte half of the 16-byte slot of channel group 2 m + lg/2
-          uint2* dp = reinterpret_cast<uint2*>(&dst[(2 * (m0 + m) + (lg >> 1)) * G::kPlane + pr.bidx[u] * kBS + pr.slot[u]]) + (lg & 1);
-          if (is_second) {
-            const uint2 old = *dp;   // bf16 x4: widen by shifting into the f32 exponent/mantissa
-            const float o0 = __uint_as_float(old.x << 16), o1 = __uint_as_float(old.x & 0xffff0000u);
-            const float o2 = __uint_as_float(old.y << 16), o3 = __uint_as_float(old.y & 0xffff0000u);
-            v[0] = o0 + fmaxf(v[0], 0.f); v[1] = o1 + fmaxf(v[1], 0.f);
-            v[2] = o2 + fmaxf(v[2], 0.f); v[3] = o3 + fmaxf(v[3], 0.f);
-          }
-          const bf16x4 o = __builtin_convertvector(v, bf16x4);
-          *dp = __builtin_bit_cast(uint2, o);
-        }
+    for (int m = 0; m < MTW; m++) {
+      f32x4 v = acc[a][m];
+      if (kSecond) {
+        const uint2 o = kPrefetch ? old[a][m] : *out_ptr(e_slot[a], m);   // bf16 x4: widen by shifting into the f32 exponent/mantissa
+        const float o0 = __uint_as_float(o.x << 16), o1 = __uint_as_float(o.x & 0xffff0000u);
+        const float o2 = __uint_as_float(o.y << 16), o3 = __uint_as_float(o.y & 0xffff0000u);
+        v[0] = o0 + fmaxf(v[0], 0.f); v[1] = o1 + fmaxf(v[1], 0.f);
+        v[2] = o2 + fmaxf(v[2], 0.f); v[3] = o3 + fmaxf(v[3], 0.f);
       }
+      const bf16x4 o = __builtin_convertvector(v, bf16x4);
+      if (valid) *out_ptr(e_slot[a], m) = __builtin_bit_cast(uint2, o);
     }
   };
 
-  uint4 f0[TPP][kSteps];
-  for (int tile = tile_lo; tile < tile_hi; tile += TPP) {
-    Pair pa;
-    geom(tile, pa);
-    load_frags(pa, f0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(pa, f0);
-    epilogue(pa);
-    if (tile + TPP >= tile_hi) after_last_pair();      // after the last epilogue: fewer live registers
+  load_frags(0, 0);
+  if (kPrefetch) {
+#pragma unroll
+    for (int g = 0; g < G_TILES; g++) {
+      const int a = g & 1, f = g & 1;
+      start_tile(g, a);
+      if (g + 1 < G_TILES) load_frags(g + 1, f ^ 1);                  // in flight under this tile's MFMAs
+      mfmas(f, a);
+      if (g >= 1) epilogue(a ^ 1);                                    // the previous tile's: scheduled among the MFMAs above
+    }
+    epilogue((G_TILES - 1) & 1);
+  } else {
+    // C = 64: a wavefront's weights alone are 144 registers -- one fragment set, one accumulator set
+#pragma unroll
+    for (int g = 0; g < G_TILES; g++) {
+      start_tile(g, 0);
+      mfmas(0, 0);
+      epilogue(0);
+      if (g + 1 < G_TILES) load_frags(g + 1, 0);
+    }
   }
+  after_last_tile();                                                  // after the last epilogue: fewer live registers
 }
 
 // MS = 1: every wavefront computes all C/16 output-channel tiles of its cell tiles.  MS = 2 (C = 64):
 // the output-channel tiles are split over two wavefronts that share the cell tiles, which halves the
 // weights a wavefront holds (144 instead of 288 registers) so that two wavefronts fit on a SIMD.
-template <int C, int NB, int NT, int TPP, int MS>
+// One layer's weight fragments, global -> LDS by DMA in the MUBUF form (buffer_load ... lds): KW pieces of
+// 1 KB shared out over the workgroup's wavefronts.  (A function of its own, not a lambda in the kernel:
+// with the buffer-resource builtins inside a kernel-body lambda hipcc 7.2 silently drops the kernel's host stub.)
+template <int KW, int NWAVES>
+__device__ __forceinline__ void dma_weights(const void* w, uint32_t bytes, uint4* lds_dst, int first_frag, int wave, int lane) {
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, (int)bytes, 0x00020000);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  for (int c = wave_u; c < KW; c += NWAVES)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds_dst + c * 64), 16, lane * 16, (first_frag + c) * 1024, 0, 0);
+}
+
+template <int C, int NB, int NT, int MS>
 __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   using G = Geo<C, NB>;
   constexpr int MTW = G::MT / MS;
@@ -226,11 +252,8 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   // C = 32: LDS stage for one layer's fragments, same [t][m][kc][lane] order as global memory
   uint4* Wst = T + G::kBufSlots;
   auto stage_layer_weights = [&](int layer) __attribute__((always_inline)) {  // global -> LDS DMA, 1 KB per instruction
-    if (layer > n_layers) return;
-    const uint4* wl = reinterpret_cast<const uint4*>(p.w) + (size_t)(layer - 1) * G::kWFrags * 64;
-    for (int c = wave; c < G::kWFrags; c += NT / 64)
-      __builtin_amdgcn_global_load_lds((const void*)(wl + c * 64 + lane),
-                                       (__attribute__((address_space(3))) void*)(Wst + ((layer & 1) * G::kWFrags + c) * 64), 16, 0, 0);
+    if (layer <= n_layers)
+      dma_weights<G::kWFrags, NT / 64>(p.w, 2u * p.n_blocks * G::kWFrags * 1024u, Wst + (layer & 1) * G::kWFrags * 64, (layer - 1) * G::kWFrags, wave, lane);
   };
   auto fetch_staged_weights = [&](int layer) __attribute__((always_inline)) {
     const uint4* ws = Wst + (layer & 1) * G::kWFrags * 64;
@@ -260,12 +283,13 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
 
   // tiles of this wave: a contiguous range
   constexpr int kWaves = NT / 64 / MS;             // wavefronts (or MS-groups of them) that share out the cell tiles
-  constexpr int kTilesPerWave = (G::kTiles + kWaves - 1) / kWaves;
+  static_assert(G::kTiles % kWaves == 0, "every wavefront owns the same number of cell tiles");
+  constexpr int kTilesPerWave = G::kTiles / kWaves;
+  constexpr bool kPrefetch = (C == 32);            // a second fragment set: 36 more registers at C = 32, 72 at C = 64 (too many)
   const int tile_lo = (wave / MS) * kTilesPerWave;
-  const int tile_hi = (tile_lo + kTilesPerWave < G::kTiles) ? tile_lo + kTilesPerWave : G::kTiles;
 
   // conv0: input image (T) -> X
-  tower_layer<C, NB, true, TPP, MTW>(T, X, wf, p.bias, false, tile_lo, tile_hi, m0, lane, [&]() __attribute__((always_inline)) {
+  tower_layer<C, NB, true, false, kTilesPerWave, MTW, kPrefetch>(T, X, wf, p.bias, tile_lo, m0, lane, [&]() __attribute__((always_inline)) {
     if (!G::kStageW && n_layers >= 1) load_layer_weights(1);
   });
   if (G::kStageW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's share of the staged layer has landed
@@ -278,11 +302,11 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
       stage_layer_weights(layer + 1);
       fetch_staged_weights(layer);
     }
-    tower_layer<C, NB, false, TPP, MTW>(
-        is_second ? T : X, is_second ? X : T, wf, p.bias + (size_t)layer * C, is_second, tile_lo, tile_hi, m0, lane,
-        [&]() __attribute__((always_inline)) {
-          if (!G::kStageW && layer < n_layers) load_layer_weights(layer + 1);
-        });
+    auto next_weights = [&]() __attribute__((always_inline)) {
+      if (!G::kStageW && layer < n_layers) load_layer_weights(layer + 1);
+    };
+    if (is_second) tower_layer<C, NB, false, true, kTilesPerWave, MTW, kPrefetch>(T, X, wf, p.bias + (size_t)layer * C, tile_lo, m0, lane, next_weights);
+    else tower_layer<C, NB, false, false, kTilesPerWave, MTW, kPrefetch>(X, T, wf, p.bias + (size_t)layer * C, tile_lo, m0, lane, next_weights);
     if (G::kStageW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -300,10 +324,10 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   }
 }
 
-template <int C, int NB, int NT, int A, int B>
+template <int C, int NB, int NT, int MS>
 int launch_tower(const TowerParams& p, uint32_t n_boards, hipStream_t stream, int device) {
   constexpr int kLds = Geo<C, NB>::kLdsBytes;
-  auto k = c4_conv_tower_kernel<C, NB, NT, A, B>;
+  auto k = c4_conv_tower_kernel<C, NB, NT, MS>;
   hipError_t e = c4host::opt_in_lds((const void*)k, kLds, device);
   if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: LDS opt-in (") + std::to_string(kLds) + " bytes) on device " + std::to_string(device) + ": " + hipGetErrorString(e));
   k<<<dim3((n_boards + NB - 1) / NB), dim3(NT), kLds, stream>>>(p);
@@ -331,30 +355,21 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   c4host::DeviceGuard guard(device);
   if (guard.error() != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: hipSetDevice: ") + hipGetErrorString(guard.error()));
   TowerParams p{(const uint16_t*)planes_dev, (const bf16x8*)w0_dev, (const bf16x8*)w_dev, bias_dev, (uint16_t*)out_dev, n_boards, n_blocks};
-  // experiment knob (tools/tower_probe.py): other wavefront counts / tiles in flight for the 32-channel tower
+  // experiment knob (tools/tower_ab.sh): 1 = 12 wavefronts per workgroup (27.3 vs 28.0 us alone at 2 048 boards, no
+  // difference in the bench), 7 = the 8-board variant at every size
   static const int variant = [] { const char* e = getenv("C4_TOWER_VARIANT"); return e ? atoi(e) : 0; }();
-  if (channels == 32 && variant) {
-    switch (variant) {
-      case 1: return launch_tower<32, 16, 768, 2, 1>(p, n_boards, (hipStream_t)stream, device);    // 12 wavefronts, 4 tiles each
-      case 2: return launch_tower<32, 16, 1024, 1, 1>(p, n_boards, (hipStream_t)stream, device);   // 16 wavefronts, 3 tiles each, one in flight
-      case 3: return launch_tower<32, 16, 512, 3, 1>(p, n_boards, (hipStream_t)stream, device);    // 8 wavefronts, three tiles in flight
-      case 4: return launch_tower<32, 16, 512, 1, 1>(p, n_boards, (hipStream_t)stream, device);    // 8 wavefronts, one tile in flight
-      case 5: return launch_tower<32, 16, 768, 1, 1>(p, n_boards, (hipStream_t)stream, device);    // 12 wavefronts, one tile in flight
-      case 6: return launch_tower<32, 16, 768, 4, 1>(p, n_boards, (hipStream_t)stream, device);    // 12 wavefronts, all four tiles in flight
-      case 7: return launch_tower<32, 8, 512, 3, 1>(p, n_boards, (hipStream_t)stream, device);     // the small-launch variant
-      default: break;
-    }
-  }
+  if (channels == 32 && variant == 1) return launch_tower<32, 16, 768, 1>(p, n_boards, (hipStream_t)stream, device);
+  if (channels == 32 && variant == 7) return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32 && n_boards <= 8 * 160)
     // small launches (up to 1 280 boards): 8 boards per workgroup, three tiles in flight per wave, so
     // that the launch spreads over twice as many CUs (2 048 boards alone: 31.6 -> 20.5 us).  NOT used for
     // the 2 048-board launches of two concurrent sessions: there the other session fills the rest of
     // the chip and what counts is CU-time per board, which is 30 % higher this way (measured: -1.7 %
     // games/s at BASELINE config 2).
-    return launch_tower<32, 8, 512, 3, 1>(p, n_boards, (hipStream_t)stream, device);
+    return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32)
-    return launch_tower<32, 16, 512, 2, 1>(p, n_boards, (hipStream_t)stream, device);   // 8 waves: two per SIMD, measured best (49 -> 32 us)
-  return launch_tower<64, 8, 512, 1, 2>(p, n_boards, (hipStream_t)stream, device);      // 8 wavefronts: pairs split the output channels, two per SIMD
+    return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);   // 8 waves: two per SIMD
+  return launch_tower<64, 8, 512, 2>(p, n_boards, (hipStream_t)stream, device);      // 8 wavefronts: pairs split the output channels, two per SIMD
 }
 
 }  // extern "C"

@@ -122,6 +122,8 @@ class InferenceNet:
     as the hand-written MFMA kernel `c4_conv_tower_bf16`; otherwise PyTorch-ROCm convs."""
 
     graph_safe = True  # forward() is pure device work on caller-owned outputs: may be captured in a HIP graph
+    stage_hook = None  # optional callable(stage): 0 = before the tower is launched, 2 = after it, 1 = after the first hidden layer's
+                       # GEMM is launched (session.capture_pair records / waits cross-stream events there)
 
     def __init__(self, model: ConnectFourNet, device: torch.device, dtype: torch.dtype = torch.bfloat16,
                  hip_tower: Optional[bool] = None, gemm: Optional[str] = None, gemm_config: Optional[int] = None):
@@ -186,6 +188,9 @@ class InferenceNet:
         if gemm == "hip" and not (self.hip_tower and (42 * self.channels) % 192 == 0):
             raise ValueError("gemm='hip' needs the HIP tower (bf16, 32 or 64 channels on a HIP device)")
         self.gemm = gemm
+        # every kernel of the evaluator computes a row from that row alone in one fixed order: a position's outputs do
+        # not depend on the batch (session.narrow_if_worthwhile may then narrow whenever it likes)
+        self.batch_invariant = self.hip_tower and gemm == "hip"
         # tile configuration: one number, or "wide,narrow" (the merged 2F-wide first layer, the F-wide layers); 0 = automatic
         cfg = str(gemm_config if gemm_config is not None else os.environ.get("C4A0_GEMM_CONFIG", "0")).split(",")
         self.gemm_config = (int(cfg[0]), int(cfg[-1]))
@@ -229,10 +234,17 @@ class InferenceNet:
     @torch.no_grad()
     def forward(self, planes: torch.Tensor, out_logprobs: Optional[torch.Tensor] = None,
                 out_q: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        hook = self.stage_hook
+        if hook is not None:
+            hook(0)
         x = self.tower(planes)
+        if hook is not None:
+            hook(2)
         if self.merged_w1 is not None:
             # first hidden layer of BOTH heads as one GEMM (same input, N = 2F): better tile occupancy
             h = self._linear_relu(x, self.merged_w1, self.merged_b1)
+            if hook is not None:
+                hook(1)
             f = self.merged_w1.shape[0] // 2
             p, v = h[:, :f], h[:, f:]
             pol_rest, val_rest = list(zip(self.pol_w[1:-1], self.pol_b[1:-1])), list(zip(self.val_w[1:-1], self.val_b[1:-1]))

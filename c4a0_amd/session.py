@@ -224,18 +224,24 @@ class DeviceSession:
 
     NARROW_CHECK_ROUNDS = 64   # lock-step rounds between two looks at the tail (a stream synchronisation each)
 
-    def narrow_if_worthwhile(self, multiple: int = 256) -> bool:
+    def narrow_if_worthwhile(self, multiple: int = 256, asynchronous: bool = False) -> bool:
         """Tail of a job: when every request has been started and at most half of the rows still hold
         a game, compact() the session.  True if `self.rows` changed (captured graphs are then stale).
 
-        The decision is taken from a SYNCHRONOUS read of the session's counters, and callers ask at
-        fixed round counts (NARROW_CHECK_ROUNDS), so the step at which a session narrows is a function of
-        the games alone, not of host or GPU timing: the evaluator's batch shape at every step -- on which
-        a library GEMM's low bits can depend -- is reproducible run to run."""
+        asynchronous=False: the decision is taken from a SYNCHRONOUS read of the session's counters, and
+        callers ask at fixed round counts (NARROW_CHECK_ROUNDS), so the step at which a session narrows
+        is a function of the games alone, not of host or GPU timing: with an evaluator whose low bits
+        depend on the batch shape (a library GEMM) the job stays reproducible run to run.
+        asynchronous=True (evaluators that declare `batch_invariant`, e.g. InferenceNet with the hand-written
+        GEMMs): the samples do not depend on when the session narrows, so the decision reads the pinned
+        progress probe instead -- no stream synchronisation, no drained run-ahead."""
         if getattr(self, "leaf_models", None) is not None or self.rows <= multiple:
             return False
-        c = self.counters()                     # synchronises this session's stream
-        done, started = c["games_done"], c["games_started"]
+        if asynchronous:
+            done, started, _err = self.progress()   # as of an earlier step: at worst the narrowing comes a few rounds later
+        else:
+            c = self.counters()                     # synchronises this session's stream
+            done, started = c["games_done"], c["games_started"]
         if started < self.n_games or (self.n_games - done) > self.rows // 2:
             return False
         before = self.rows
@@ -283,7 +289,8 @@ class DeviceSession:
                 if done >= self.n_games:
                     break
                 chunks += 1
-                if graph is not None and chunks % max(1, self.NARROW_CHECK_ROUNDS // steps_per_graph) == 0 and self.narrow_if_worthwhile():
+                if graph is not None and chunks % max(1, self.NARROW_CHECK_ROUNDS // steps_per_graph) == 0 and \
+                        self.narrow_if_worthwhile(asynchronous=bool(getattr(evaluator, "batch_invariant", False))):
                     inflight.clear()
                     graph = self.capture_steps(evaluator, steps_per_graph)   # the old graph carries the old width
             if max_steps is not None and steps >= max_steps:
@@ -295,6 +302,79 @@ class DeviceSession:
         if c["error"]:
             raise C4Error(c["error"], f"raised on device by slot {c['error_slot']}")
         return steps
+
+
+def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cuda.Stream], evaluator, steps_per_graph: int = 32
+                 ) -> "torch.cuda.CUDAGraph":
+    """TWO sessions' rounds captured into ONE HIP graph with an explicit software pipeline between them.
+
+    Two sessions that replay independent graphs on two streams settle into whatever relative phase the
+    contention between them happens to lock: measured on MI355X the same binary runs at 22.5 k or 25.7 k
+    games/s (and a faster tower moved it to 23.1 k or 27.5 k) depending on that phase -- in phase, both
+    sessions' latency-bound kernels (head outputs, step kernel) leave the chip idle together.  Here the
+    phase is part of the graph: session B's [tower, first hidden layer] may start only when session A's
+    has finished, and A's next [tower, first layer] only when B's has -- the two heavy halves strictly
+    alternate, each running beside the OTHER session's [narrow layers, head outputs, step kernel].
+    Cross-stream events recorded and awaited during capture become edges of the graph; nothing else
+    changes (same kernels, same per-session order, same samples).
+
+    `evaluator` must be a c4a0_amd.nn.InferenceNet (its `stage_hook` marks the two points).  The graph
+    is replayed on streams[0]; both sessions stay bound to their streams."""
+    a, b = sessions
+    s0, s1 = streams
+    dev = a.device
+    for s in sessions:
+        s.set_timing(False)
+    # warm the evaluator up outside the capture, once per stream (library handles, lazy module loads)
+    for s, st in zip(sessions, streams):
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(st)
+        with torch.cuda.stream(side):
+            s.bind(side)
+            for _ in range(2):
+                s.evaluate(evaluator)
+        st.wait_stream(side)
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    prev_hook = getattr(evaluator, "stage_hook", None)
+    try:
+        with torch.cuda.graph(graph, stream=s0):
+            a.bind(s0)
+            b.bind(s1)
+            s1.wait_stream(s0)                                  # fork: s1 joins the capture
+            ev_b_prev = None
+            import os
+            mode = int(os.environ.get("C4_PAIR_MODE", "1"))     # experiment knob: where the hand-over points sit
+            sig = 2 if mode in (2, 5) else 1                    # signal after the tower (2) or after the first hidden layer (1)
+            for r in range(steps_per_graph):
+                ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
+                first_only = mode in (4, 5) and r > 0           # modes 4/5: offset the sessions once per graph, then run free
+
+                def hook_a(stage, ev_a=ev_a, wait_for=ev_b_prev, free=first_only or mode == 3):
+                    if stage == 0 and wait_for is not None and not free:
+                        s0.wait_event(wait_for)                 # A's heavy half after B's previous one
+                    elif stage == sig:
+                        ev_a.record(s0)
+
+                def hook_b(stage, ev_a=ev_a, ev_b=ev_b, free=first_only):
+                    if stage == 0 and not free:
+                        s1.wait_event(ev_a)                     # B's heavy half after A's
+                    elif stage == sig:
+                        ev_b.record(s1)
+
+                evaluator.stage_hook = hook_a
+                with torch.cuda.stream(s0):
+                    a.evaluate(evaluator)
+                    a.step()
+                evaluator.stage_hook = hook_b
+                with torch.cuda.stream(s1):
+                    b.evaluate(evaluator)
+                    b.step()
+                ev_b_prev = ev_b
+            s0.wait_stream(s1)                                  # join
+    finally:
+        evaluator.stage_hook = prev_hook
+    return graph
 
 
 def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator, steps_per_graph: int = 8,
@@ -312,6 +392,8 @@ def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator
     dev = sessions[0].device
     streams = [torch.cuda.Stream(device=dev) for _ in sessions]
     cur = torch.cuda.current_stream(dev)
+    invariant = bool(getattr(evaluator, "batch_invariant", False))
+    paired = len(sessions) == 2 and hasattr(evaluator, "stage_hook")
     graphs = []
     for s, st in zip(sessions, streams):
         st.wait_stream(cur)
@@ -319,7 +401,10 @@ def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator
             s.bind(st)
             s.start()
         st.synchronize()
-        graphs.append(s.capture_steps(evaluator, steps_per_graph, stream=st))
+        if not paired:
+            graphs.append(s.capture_steps(evaluator, steps_per_graph, stream=st))
+    if paired:
+        return _run_pair(sessions, streams, evaluator, steps_per_graph, max_chunks_in_flight, invariant)
     steps = [0] * len(sessions)
     chunks = [0] * len(sessions)
     live = [s.n_games > 0 for s in sessions]
@@ -343,7 +428,7 @@ def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator
             chunks[i] += 1
             if done >= s.n_games:
                 live[i] = False
-            elif chunks[i] % max(1, s.NARROW_CHECK_ROUNDS // steps_per_graph) == 0 and s.narrow_if_worthwhile():   # tail: fewer rows to evaluate, see DeviceSession.compact
+            elif chunks[i] % max(1, s.NARROW_CHECK_ROUNDS // steps_per_graph) == 0 and s.narrow_if_worthwhile(asynchronous=invariant):   # tail: fewer rows to evaluate, see DeviceSession.compact
                 inflight[i].clear()
                 graphs[i] = s.capture_steps(evaluator, steps_per_graph, stream=st)
     torch.cuda.synchronize(dev)
@@ -351,6 +436,48 @@ def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator
         s.set_timing(True)
         s.raise_if_device_error()
     return steps
+
+
+def _run_pair(sessions, streams, evaluator, steps_per_graph, max_chunks_in_flight, invariant) -> List[int]:
+    """run_sessions for two sessions of an InferenceNet: ONE graph that pipelines the two explicitly
+    (capture_pair), replayed until both sessions' games are over.  A session that finishes first keeps
+    stepping its idle slots until the other is done (its rows are narrowed away like any tail)."""
+    dev = sessions[0].device
+    graph = capture_pair(sessions, streams, evaluator, steps_per_graph)
+    steps = 0
+    chunks = 0
+    inflight: List[torch.cuda.Event] = []
+    while True:
+        with torch.cuda.stream(streams[0]):
+            graph.replay()
+            ev = torch.cuda.Event()
+            ev.record(streams[0])
+        steps += steps_per_graph
+        inflight.append(ev)
+        if len(inflight) > max_chunks_in_flight:   # bounded host run-ahead, as in DeviceSession.run
+            inflight.pop(0).synchronize()
+        done_all = True
+        for s, st in zip(sessions, streams):
+            with torch.cuda.stream(st):
+                done, err = s.poll()
+            if err:
+                torch.cuda.synchronize(dev)
+                s.raise_if_device_error()
+            done_all = done_all and done >= s.n_games
+        if done_all:
+            break
+        chunks += 1
+        if chunks % max(1, sessions[0].NARROW_CHECK_ROUNDS // steps_per_graph) == 0:
+            narrowed = [s.narrow_if_worthwhile(asynchronous=invariant) for s in sessions]
+            if any(narrowed):   # the old graph carries the old widths
+                inflight.clear()
+                torch.cuda.synchronize(dev)
+                graph = capture_pair(sessions, streams, evaluator, steps_per_graph)
+    torch.cuda.synchronize(dev)
+    for s in sessions:
+        s.set_timing(True)
+        s.raise_if_device_error()
+    return [steps, steps]
 
 
 SAMPLE_DTYPE = np.dtype([("game_id", "<u8"), ("mask", "<u8"), ("value", "<u8"), ("policy", "<f4", (7,)),
