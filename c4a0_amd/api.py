@@ -67,8 +67,7 @@ class _CallbackEvaluator:
         self.multi = self.models_used.size > 1
         self.slot_models = session.bind_leaf_models() if self.multi else None   # the step kernel publishes mcts.rs:70-76 per slot
         self.arange = torch.arange(g, dtype=torch.int64, device=dev)
-        # pinned staging: unique input rows out, unique answers back
-        self.h_planes = torch.empty((g, 2, 6, 7), dtype=torch.float32).pin_memory()
+        # pinned staging of the unique answers on their way back (the input batches are fresh pinned arrays, see __call__)
         self.h_out = torch.empty((g, 9), dtype=torch.float32).pin_memory()
         self.d_out = torch.empty((g, 9), dtype=torch.float32, device=dev)
         self.nn_positions = 0
@@ -78,22 +77,30 @@ class _CallbackEvaluator:
     def __call__(self, _planes: torch.Tensor):
         s, C = self.s, self._C
         self._check(s.L.c4_session_leaf_keys(s._h, C.c_void_p(self.keys.data_ptr())))
-        if self.multi:   # group by model first: rows sort as (model, position)
-            rows = torch.stack([torch.where(self.keys >= 0, self.slot_models, torch.full_like(self.keys, -1)), self.keys], dim=1)
+        if self.multi:   # group by model first: rows sort as (idle?, model, position)
+            # idle slots are marked by a column of their own, not by a model id: every 64-bit id is a valid model
+            # (ids >= 2^63 are negative as int64 bit patterns; they still sort into one run per model)
+            idle = self.keys < 0
+            zero = torch.zeros_like(self.keys)
+            rows = torch.stack([idle.to(torch.int64), torch.where(idle, zero, self.slot_models), torch.where(idle, zero - 1, self.keys)], dim=1)
             uniq, inv = torch.unique(rows, dim=0, return_inverse=True)
-            u_models, u_keys = uniq[:, 0], uniq[:, 1]
+            u_models, u_keys = uniq[:, 1], uniq[:, 2]
         else:
             u_keys, inv = torch.unique(self.keys, return_inverse=True)
             u_models = None
         n_u = u_keys.shape[0]
         # any slot holding a unique position stands for it: take its row of the evaluator input
         first = torch.empty(n_u, dtype=torch.int64, device=s.device).scatter_(0, inv, self.arange)
-        self.h_planes[:n_u].copy_(s.planes.index_select(0, first), non_blocking=True)
+        # A FRESH pinned array per step (PyTorch's caching host allocator: no system call after warm-up), as the
+        # reference hands its callback a new array it owns (pybridge.rs:220 into_pyarray): a callback that keeps x
+        # keeps this block alive, nothing it was given is ever overwritten.  Still one PCIe transfer.
+        h_planes = torch.empty((n_u, 2, 6, 7), dtype=torch.float32, pin_memory=True)
+        h_planes.copy_(s.planes.index_select(0, first), non_blocking=True)
         keys_h = u_keys.cpu().numpy()              # synchronises: the rows above have landed too
         live = keys_h >= 0                         # idle slots share the key -1
         if live.any():
             models_h = u_models.cpu().numpy() if self.multi else None
-            planes_np, out_np = self.h_planes.numpy(), self.h_out.numpy()
+            planes_np, out_np = h_planes.numpy(), self.h_out.numpy()
             # runs of one model (rows are sorted by model, then position), without the idle row
             if self.multi:
                 cuts = np.flatnonzero(np.diff(models_h)) + 1
@@ -101,11 +108,13 @@ class _CallbackEvaluator:
             else:
                 groups = [(0, n_u)]
             for lo, hi_model in groups:
-                while lo < hi_model and not live[lo]:
+                while lo < hi_model and not live[lo]:          # single-model mode: the idle key -1 sorts first
                     lo += 1
+                while hi_model > lo and not live[hi_model - 1]:  # multi-model mode: the idle row sorts last
+                    hi_model -= 1
                 if lo >= hi_model:
                     continue
-                mid = int(np.uint64(models_h[lo])) if self.multi else int(self.models_used[0])
+                mid = (int(models_h[lo]) & ((1 << 64) - 1)) if self.multi else int(self.models_used[0])
                 for i in range(lo, hi_model, self.cap):
                     j = min(i + self.cap, hi_model)
                     out = self.cb(mid, planes_np[i:j])

@@ -1124,13 +1124,15 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   uint32_t n_ln = cfg->n_mcts_iterations + 64u;
   n_ln = n_ln < 1024u ? 1024u : (n_ln > 65536u ? 65536u : n_ln);
   hipError_t e;
+  // one row of phase stamps per wavefront plus one per timing-helper workgroup (one helper per kWavesPerTimingHelper wavefronts)
+  const size_t phase_rows = (size_t)s->n_waves_cap + (s->n_waves_cap + kWavesPerTimingHelper - 1) / kWavesPerTimingHelper + 1;
   if ((e = hipMalloc(&p.slots, n * sizeof(Slot))) != hipSuccess ||
       (e = hipMalloc(&p.blocks, n * bps * sizeof(Block))) != hipSuccess ||
       (e = hipMalloc(&p.wave_ctr, (size_t)s->n_waves_cap * CTR_N * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.glob, sizeof(Globals))) != hipSuccess ||
       (e = hipMalloc(&p.stamps, (size_t)s->n_waves_cap * 4 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.clock_acc, 5 * sizeof(unsigned long long))) != hipSuccess ||
-      (e = hipMalloc(&p.phase, ((size_t)s->n_waves_cap + 64) * 16 * sizeof(unsigned long long))) != hipSuccess ||   // + the timing helper workgroups (diagnostic builds stamp them too)
+      (e = hipMalloc(&p.phase, phase_rows * 16 * sizeof(unsigned long long))) != hipSuccess ||   // + the timing helper workgroups (diagnostic builds stamp them too)
       (e = hipMalloc(&s->ln_tab_dev, (size_t)n_ln * sizeof(float))) != hipSuccess ||
       (e = hipHostMalloc(&s->probe_host, sizeof(Globals))) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s->probe_event, hipEventDisableTiming)) != hipSuccess)
@@ -1144,7 +1146,7 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(p.stamps, 0, (size_t)s->n_waves_cap * 4 * sizeof(unsigned long long)));
   HIP_TRY(reset_clock_acc(p.clock_acc));
-  HIP_TRY(hipMemset(p.phase, 0, ((size_t)s->n_waves_cap + 64) * 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(p.phase, 0, phase_rows * 16 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(p.slots, 0, n * sizeof(Slot)));
   HIP_TRY(hipMemset(p.glob, 0, sizeof(Globals)));
   HIP_TRY(hipMemset(p.wave_ctr, 0, (size_t)s->n_waves_cap * CTR_N * sizeof(unsigned long long)));

@@ -378,9 +378,15 @@ class PlayGamesResult:
         np.random.Generator(np.random.PCG64(int(seed) & ((1 << 64) - 1))).shuffle(results)
         # (len as f32 * train_frac).round(): f32 product, then Rust's f32::round = half AWAY from zero
         # (np.round is half-to-even: 5 games at 0.5 must give 3, not 2)
+        # ... and Rust's `as usize` saturates: NaN -> 0, negative -> 0, +inf / too large -> usize::MAX (then the
+        # slice bound is clamped to len here, where the reference would panic on an out-of-range split)
         prod = float(np.float32(len(results)) * np.float32(train_frac))
-        n_train = int(math.floor(prod + 0.5)) if prod >= 0.0 else -int(math.floor(-prod + 0.5))
-        n_train = max(0, min(len(results), n_train))
+        if math.isnan(prod) or prod <= 0.0:
+            n_train = 0
+        elif math.isinf(prod):
+            n_train = len(results)
+        else:
+            n_train = min(len(results), int(math.floor(prod + 0.5)))
         train = [s for r in results[:n_train] for s in r.samples]
         test = [s for r in results[n_train:] for s in r.samples]
         return train, test

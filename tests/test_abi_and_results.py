@@ -138,6 +138,16 @@ def test_split_train_test_rounds_half_away_from_zero():
         assert (len(tr), len(te)) == (want, n - want), (n, frac)
 
 
+def test_split_train_test_saturates_like_rust_as_usize():
+    """`.round() as usize` saturates (NaN -> 0, negative -> 0, +inf -> max): no exception here either."""
+    from c4a0_amd import GameMetadata, GameResult, PlayGamesResult, Sample
+    mk = lambda i: GameResult(GameMetadata(i, 0, 0), [Sample(1 << i, 0, [1 / 7] * 7, 0.0, 0.0)])
+    res = PlayGamesResult([mk(i) for i in range(4)])
+    for frac, want in [(float("nan"), 0), (-1.0, 0), (float("-inf"), 0), (float("inf"), 4), (1e30, 4), (2.0, 4)]:
+        tr, te = res.split_train_test(frac, 3)
+        assert (len(tr), len(te)) == (want, 4 - want), frac
+
+
 def test_results_from_records_roundtrip():
     from c4a0_amd import GameMetadata
     from c4a0_amd.results import results_from_records
