@@ -493,6 +493,15 @@ def main():
             except Exception:
                 traffic = None
         fl = flops_per_leaf(cfg)
+        mfma_busy, mfma_src = None, None   # counters under the evaluator: not re-measured here, read from the committed PMC summary
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_evaluator_pmc.json")))
+            mfma_busy = pm["backends"]["hip0" if net.gemm == "hip" else "hipblaslt0"]["evaluator_mfma_busy_frac_of_chip_time_weighted"]
+            mfma_src = ("profiles/r03_evaluator_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles), time-weighted over the tower, the three "
+                        "hidden-layer GEMMs and the output kernel, each launch ALONE on the chip at 2 048 rows (rocprofv3 --pmc serialises kernels); "
+                        "not re-measured in this run")
+        except Exception:
+            pass
         out = {
             "metric": "self-play games/sec (and MCTS sims/sec) at n_mcts=100",
             "value": games / elapsed_max,
@@ -541,7 +550,8 @@ def main():
             "nn": {"bound": "mfma", "flops_per_leaf": fl, "achieved": fl * G * timed_rounds / elapsed / 1e12,
                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": fl * G * timed_rounds / elapsed / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                   "note": "evaluator FLOPs over the WHOLE wall time of the timed steps (tree kernels and launch gaps included): a lower bound on the evaluator's own rate"},
+                   "note": "evaluator FLOPs over the WHOLE wall time of the timed steps (tree kernels and launch gaps included): a lower bound on the evaluator's own rate",
+                   "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src, "hidden_layer_gemm": net.gemm},
         }
         if allgather is not None:
             out["sample_allgather"] = allgather

@@ -261,6 +261,8 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
     # longer graphs amortise the replay boundary (+2.5 % at 32); all but very long jobs keep the finer
     # stop granularity (a 16 384-game job: 16.0 k games/s at 8 steps per graph, 14.9 k at 32)
     steps_per_graph = (32 if len(reqs) >= 32 * n_slots else 8) if graph_safe else 0
+    if hasattr(evaluator, "latency_mode"):   # InferenceNet: tile choice of the narrow layers, alone vs beside another session
+        evaluator.latency_mode = parts == 1
     sessions = []
     try:
         for p in range(parts):   # session p plays requests p, p + parts, ...

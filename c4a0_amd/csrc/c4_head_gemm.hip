@@ -215,6 +215,185 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmPa
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same GEMM with 32-deep k-tiles (64-byte LDS rows), for tiles too big for three 64-deep stages:
+// 256 x 192 pulls 30 % fewer operand bytes out of L2 per flop than 128 x 192 -- and L2 -> LDS bytes, not
+// MFMA issue, are what bounds these layers (profiles/r03_evaluator_pmc.json) -- but a 64-deep stage of
+// it is 56 KB.  Differences from the kernel above:
+//   * a DMA piece is 16 rows x 64 bytes; slot g of row r lives at g ^ T[(r >> 2) & 3], T = {0, 2, 3, 1}
+//     (conflict-free for every ds_read_b128 lane group: rows 4 apart share a bank row);
+//   * one MFMA k-step per k-tile, so the fragment reads are skewed by a k-tile instead of by half of
+//     one: after the barrier that publishes k-tile kt its fragments are requested into one register set
+//     while the MFMAs of k-tile kt - 1 run from the other;
+//   * the pieces of a k-tile need not divide evenly over the wavefronts (28 over 8): the first few
+//     wavefronts issue one more, and each waits for its own count.
+// Every output element still sees the same chain (k ascending, 32 at a time): same bits as above.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(64 * WM * WN, 1) void c4_head_gemm32_kernel(GemmParams p) {
+  constexpr int BKT = 32;
+  constexpr int kWaves = WM * WN;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int kStageBytes = (BM + BN) * BKT * 2;
+  constexpr int kChunks = (BM + BN) / 16;                     // 1 KB pieces (16 rows x 64 bytes) per k-tile
+  constexpr int L = (kChunks + kWaves - 1) / kWaves;          // pieces of the wavefronts that issue the most
+  constexpr int R = kChunks % kWaves;                         // wavefronts 0 .. R - 1 issue L, the others L - 1 (R == 0: all L)
+  static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && NSTAGE >= 3 && NSTAGE <= 4, "tile / ring");
+  extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int li = lane & 15, lg = lane >> 4;
+  const bool short_wave = R != 0 && wave >= R;                // issues L - 1 pieces per k-tile
+
+  int tm, tn;
+  {
+    const int b = blockIdx.x;
+    if (p.xm) {
+      const int rm = p.tiles_m / p.xm, rn = p.tiles_n / p.xn;
+      const int xcd = b & 7, idx = b >> 3;
+      tm = (xcd / (int)p.xn) * rm + idx / rn;
+      tn = (xcd % (int)p.xn) * rn + idx % rn;
+    } else {
+      tm = b / (int)p.tiles_n;
+      tn = b % (int)p.tiles_n;
+    }
+  }
+  const int tm0 = tm * BM, tn0 = tn * BN;
+
+  auto swz = [](int row) __attribute__((always_inline)) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; };   // T = {0, 2, 3, 1}
+  uint32_t src_off[L];
+  const int r16 = lane >> 2, slot = lane & 3;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    int c = wave + kWaves * i;
+    c = c < kChunks ? c : kChunks - 1;                        // a short wavefront's surplus entry is never issued
+    if (c < BM / 16) {
+      const int row = c * 16 + r16;
+      int gr = tm0 + row;
+      gr = gr < (int)p.M ? gr : (int)p.M - 1;
+      src_off[i] = (uint32_t)gr * p.ldx * 2u + (uint32_t)((slot ^ swz(row)) * 16);
+    } else {
+      const int row = (c - BM / 16) * 16 + r16;
+      src_off[i] = (uint32_t)(tn0 + row) * p.K * 2u + (uint32_t)((slot ^ swz(row)) * 16);
+    }
+  }
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.M * p.ldx * 2u), 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(p.N * p.K * 2u), 0x00020000);
+  auto issue_one = [&](int kt, int i) __attribute__((always_inline)) {
+    if (i == L - 1 && short_wave) return;
+    uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
+    const int c = wave + kWaves * i;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((c < BM / 16) ? x_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)(st + c * 1024), 16,
+                                             (int)src_off[i], kt * (BKT * 2), 0, 0);
+  };
+  auto wait_tile = [&]() __attribute__((always_inline)) {     // all but the (NSTAGE - 2) youngest k-tiles of THIS wavefront have landed
+    if (short_wave) wait_vmcnt<(NSTAGE - 2) * (L - 1)>(); else wait_vmcnt<(NSTAGE - 2) * L>();
+    // the fragment reads of the previous k-tile (consumed only in THIS iteration) must have returned before the
+    // barrier lets anybody's DMA overwrite their buffer; they were issued a whole MFMA group ago
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; a++)
+#pragma unroll
+    for (int b = 0; b < TM; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t frag_off = (uint32_t)li * 64u + (uint32_t)((lg ^ swz(li)) * 16);   // row = tile base (multiple of 16) + li
+  const uint32_t x_base = (uint32_t)(wm * (BM / WM)) * 64u;
+  const uint32_t w_base = (uint32_t)(BM * BKT * 2) + (uint32_t)(wn * (BN / WN)) * 64u;
+
+  const int KT = (int)p.K / BKT;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; s++) {
+#pragma unroll
+    for (int i = 0; i < L; i++) issue_one(s, i);
+  }
+
+  bf16x8 afr[2][TN], bfr[2][TM];
+  auto read_frags = [&](int kt, int f) __attribute__((always_inline)) {
+    const uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
+#pragma unroll
+    for (int b = 0; b < TM; b++) bfr[f][b] = *reinterpret_cast<const bf16x8*>(st + x_base + frag_off + b * 1024);
+#pragma unroll
+    for (int a = 0; a < TN; a++) afr[f][a] = *reinterpret_cast<const bf16x8*>(st + w_base + frag_off + a * 1024);
+  };
+  constexpr int kLoadsPerStep = (L + TN - 1) / TN;
+  auto step = [&](int kt, int fcur, int fprev, bool do_mfma) __attribute__((always_inline)) {
+    wait_tile();
+    __builtin_amdgcn_s_barrier();                               // k-tile kt is in LDS for everybody; buffer (kt - 1) % NSTAGE is free
+    read_frags(kt, fcur);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+      if (do_mfma) {
+#pragma unroll
+        for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[fprev][a], bfr[fprev][b], acc[a][b], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = a * kLoadsPerStep; j < (a + 1) * kLoadsPerStep && j < L; j++) issue_one(kt + NSTAGE - 1, j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  step(0, 0, 1, false);
+  for (int kt = 1; kt + 1 < KT; kt += 2) {                      // KT is even (K % 64 == 0)
+    step(kt, 1, 0, true);
+    step(kt + 1, 0, 1, true);
+  }
+  step(KT - 1, 1, 0, true);
+#pragma unroll
+  for (int a = 0; a < TN; a++)                                  // the last k-tile's MFMAs
+#pragma unroll
+    for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
+  wait_vmcnt<0>();
+
+#pragma unroll
+  for (int a = 0; a < TN; a++) {
+    const int n = tn0 + wn * (BN / WN) + a * 16 + 4 * lg;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int b = 0; b < TM; b++) {
+      const int m = tm0 + wm * (BM / WM) + b * 16 + li;
+      f32x4 v = acc[a][b] + bv;
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+      }
+      const bf16x4 o = __builtin_convertvector(v, bf16x4);
+      if (m < (int)p.M) *reinterpret_cast<uint2*>(p.y + (size_t)m * p.ldy + n) = __builtin_bit_cast(uint2, o);
+    }
+  }
+}
+
+template <int BM, int BN, typename K>
+int launch_common(K k, GemmParams p, int threads, int lds_bytes, hipStream_t stream, int device) {
+  if (lds_bytes > 64 * 1024) {
+    const hipError_t e = c4host::opt_in_lds((const void*)k, lds_bytes, device);
+    if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16: LDS opt-in: ") + hipGetErrorString(e));
+  }
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = p.N / BN;
+  p.xm = p.xn = 0;
+  uint64_t best = ~0ull;
+  for (uint32_t xm = 1; xm <= 8; xm *= 2) {
+    const uint32_t xn = 8 / xm;
+    if (p.tiles_m % xm || p.tiles_n % xn) continue;
+    const uint64_t rows = (uint64_t)(p.tiles_m / xm) * BM + (uint64_t)(p.tiles_n / xn) * BN;
+    if (rows < best) { best = rows; p.xm = xm; p.xn = xn; }
+  }
+  k<<<dim3(p.tiles_m * p.tiles_n), dim3(threads), lds_bytes, stream>>>(p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16 launch: ") + hipGetErrorString(e));
+  return C4_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+int launch_gemm32(GemmParams p, hipStream_t stream, int device) {
+  return launch_common<BM, BN>(c4_head_gemm32_kernel<BM, BN, WM, WN, NSTAGE>, p, 64 * WM * WN, NSTAGE * (BM + BN) * 32 * 2, stream, device);
+}
+
 template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW>
 int launch_gemm(GemmParams p, hipStream_t stream, int device) {
   constexpr int kLds = NSTAGE * (BM + BN) * BK * 2;
@@ -262,8 +441,10 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
   // bytes out of L2 per flop of all tiles that still give every layer >= 112 workgroups, and the CUs its
   // narrow-layer launches leave free go to the other session's kernels.  Finer tilings that look better
   // alone (128 x 96: 13.5 vs 16.6 us for a 2048 x 1344 x 1344 layer) lose 8-13 % of games/s in the mix.
-  // Small batches (callback mode, tails) want many small tiles: latency, not CU-time.
-  if (config == 0) config = m <= 1024 ? 10 : 11;
+  // Small batches (callback mode, tails, jobs of a few hundred games) want many small tiles: there a
+  // layer is a latency chain, not CU-time (alone, us: M = 512 cfg 9 8.0 / 7.5 for the wide / narrow
+  // layer against cfg 11's 16.4 / 15.5; M = 1024 cfg 10 12.3 wide, cfg 9 7.9 narrow).
+  if (config == 0) config = m <= 640 ? 9 : (m <= 1024 ? (n > k ? 10 : 9) : 11);
   switch (config) {
     case 1: return launch_gemm<128, 192, 2, 2, 2, 2>(p, st, device);   // 4 wavefronts (64 x 96 each), 80 KB: two workgroups per CU
     case 2: return launch_gemm<128, 192, 2, 4, 4, 1>(p, st, device);   // 8 wavefronts (64 x 48), 4-deep ring, the whole LDS
@@ -281,6 +462,9 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     case 14: return launch_gemm<256, 96, 2, 2, 3, 1>(p, st, device);   // 4 wavefronts (128 x 48), 3-deep ring, 132 KB
     case 15: return launch_gemm<64, 192, 1, 4, 3, 1>(p, st, device);   // 4 wavefronts (64 x 48), 3-deep ring, 96 KB
     case 16: return launch_gemm<64, 192, 2, 4, 3, 1>(p, st, device);   // 8 wavefronts (32 x 48), 3-deep ring, 96 KB
+    case 17: return launch_gemm32<256, 192, 2, 4, 4>(p, st, device);   // 8 wavefronts (128 x 48), 32-deep k-tiles, 4-deep ring, 112 KB
+    case 18: return launch_gemm32<256, 192, 2, 4, 3>(p, st, device);   // ... 3-deep ring, 84 KB
+    case 19: return launch_gemm32<256, 192, 4, 2, 4>(p, st, device);   // 8 wavefronts (64 x 96), 4-deep ring
     default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
   }
 }

@@ -1480,30 +1480,25 @@ int c4_session_sample_counts(c4_session* s, uint32_t* counts_host, uint64_t n_ga
 
 int c4_session_drain_samples(c4_session* s, c4_sample_rec* dst_host, uint64_t cap, uint64_t* n_written) {
   if (!s || !n_written) return fail(C4_ERR_BAD_ARG, "null argument");
-  C4_ON_DEVICE(s->cfg.device);
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  std::vector<uint32_t> counts(s->n_games ? s->n_games : 1);
-  if (s->n_games) HIP_TRY(hipMemcpy(counts.data(), s->p.sample_counts, s->n_games * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (!s->have_games) return fail(C4_ERR_NOT_BOUND, "set_games must precede drain_samples");
+  // The records are packed ON THE DEVICE (prefix sum + K6, as for the collective) and come back in ONE
+  // transfer straight into the caller's buffer: no host-side staging of the 43-record-per-game store.
   uint64_t total = 0;
-  for (uint64_t i = 0; i < s->n_games; i++) total += counts[i];
+  int rc = c4_session_pack_samples(s, nullptr, 0, &total);   // size query: offsets + total (synchronises the stream)
+  if (rc != C4_OK) return rc;
   *n_written = total;
-  if (!dst_host) return C4_OK;  // size query
+  if (!dst_host || total == 0) return C4_OK;
   if (cap < total) return fail(C4_ERR_BAD_ARG, "destination too small");
-  // copy runs of consecutive finished games with one transfer each
-  uint64_t off = 0, i = 0;
-  std::vector<c4_sample_rec> tmp;
-  const uint64_t chunk_games = 4096;
-  while (i < s->n_games) {
-    const uint64_t j = (i + chunk_games < s->n_games) ? i + chunk_games : s->n_games;
-    tmp.resize((j - i) * C4_MAX_SAMPLES_PER_GAME);
-    HIP_TRY(hipMemcpy(tmp.data(), s->p.samples + i * C4_MAX_SAMPLES_PER_GAME, tmp.size() * sizeof(c4_sample_rec), hipMemcpyDeviceToHost));
-    for (uint64_t k = i; k < j; k++) {
-      memcpy(dst_host + off, tmp.data() + (k - i) * C4_MAX_SAMPLES_PER_GAME, (size_t)counts[k] * sizeof(c4_sample_rec));
-      off += counts[k];
-    }
-    i = j;
+  C4_ON_DEVICE(s->cfg.device);
+  c4_sample_rec* tmp = nullptr;
+  HIP_TRY(hipMalloc(&tmp, total * sizeof(c4_sample_rec)));
+  rc = c4_session_pack_samples(s, tmp, total, &total);
+  if (rc == C4_OK) {
+    const hipError_t e = hipMemcpy(dst_host, tmp, total * sizeof(c4_sample_rec), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(C4_ERR_HIP, std::string("drain_samples: copying the packed records: ") + hipGetErrorString(e));
   }
-  return C4_OK;
+  (void)hipFree(tmp);
+  return rc;
 }
 
 int c4_session_pack_samples(c4_session* s, c4_sample_rec* dst_dev, uint64_t cap, uint64_t* n_written) {

@@ -121,8 +121,11 @@ class InferenceNet:
     `hip_tower=True` (default on a HIP device in bf16 with 32 or 64 channels) runs the conv tower
     as the hand-written MFMA kernel `c4_conv_tower_bf16`; otherwise PyTorch-ROCm convs."""
 
+    latency_mode = False  # True while ONE session plays alone on the device (api._play sets it): the narrow layers of a
+                          # > 1 024-row batch then use the 128 x 96 tile (12.7 vs 16.8 us alone at 1 700 rows; beside a
+                          # second session's kernels the fat 128 x 192 tile wins, c4_head_gemm.hip)
     graph_safe = True  # forward() is pure device work on caller-owned outputs: may be captured in a HIP graph
-    stage_hook = None  # optional callable(stage): 0 = before the tower is launched, 2 = after it, 1 = after the first hidden layer's
+    stage_hook = None  # optional callable(stage): 0 = before the tower is launched, 1 = after the first hidden layer's
                        # GEMM is launched (session.capture_pair records / waits cross-stream events there)
 
     def __init__(self, model: ConnectFourNet, device: torch.device, dtype: torch.dtype = torch.bfloat16,
@@ -238,8 +241,6 @@ class InferenceNet:
         if hook is not None:
             hook(0)
         x = self.tower(planes)
-        if hook is not None:
-            hook(2)
         if self.merged_w1 is not None:
             # first hidden layer of BOTH heads as one GEMM (same input, N = 2F): better tile occupancy
             h = self._linear_relu(x, self.merged_w1, self.merged_b1)
@@ -290,7 +291,8 @@ class InferenceNet:
             m, n, k = x.shape[0], w.shape[0], w.shape[1]
             y = torch.empty((m, n), dtype=torch.bfloat16, device=self.device)
             check(self._L.c4_linear_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(self._bias32[b.data_ptr()].data_ptr()),
-                                         C.c_void_p(y.data_ptr()), m, n, k, x.stride(0), n, 1, self.gemm_config[0 if n > k else 1],
+                                         C.c_void_p(y.data_ptr()), m, n, k, x.stride(0), n, 1,
+                                         self.gemm_config[0 if n > k else 1] or (10 if (self.latency_mode and m > 1024 and n <= k) else 0),
                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             return y
         if self.fused_epilogue:

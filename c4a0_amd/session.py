@@ -316,7 +316,11 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
     has finished, and A's next [tower, first layer] only when B's has -- the two heavy halves strictly
     alternate, each running beside the OTHER session's [narrow layers, head outputs, step kernel].
     Cross-stream events recorded and awaited during capture become edges of the graph; nothing else
-    changes (same kernels, same per-session order, same samples).
+    changes (same kernels, same per-session order, same samples).  Where exactly the hand-over points sit
+    (after the tower, after the first layer, only once per graph) made no measurable difference
+    (25.2-25.3 k games/s for all of them on one box; two free-running graphs: 26.0 k in their good phase,
+    22.7-23.2 k in their bad one, one run in three): what the single graph buys is that the result no longer
+    depends on a coin toss at start-up.
 
     `evaluator` must be a c4a0_amd.nn.InferenceNet (its `stage_hook` marks the two points).  The graph
     is replayed on streams[0]; both sessions stay bound to their streams."""
@@ -343,23 +347,19 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
             b.bind(s1)
             s1.wait_stream(s0)                                  # fork: s1 joins the capture
             ev_b_prev = None
-            import os
-            mode = int(os.environ.get("C4_PAIR_MODE", "1"))     # experiment knob: where the hand-over points sit
-            sig = 2 if mode in (2, 5) else 1                    # signal after the tower (2) or after the first hidden layer (1)
-            for r in range(steps_per_graph):
+            for _ in range(steps_per_graph):
                 ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
-                first_only = mode in (4, 5) and r > 0           # modes 4/5: offset the sessions once per graph, then run free
 
-                def hook_a(stage, ev_a=ev_a, wait_for=ev_b_prev, free=first_only or mode == 3):
-                    if stage == 0 and wait_for is not None and not free:
+                def hook_a(stage, ev_a=ev_a, wait_for=ev_b_prev):
+                    if stage == 0 and wait_for is not None:
                         s0.wait_event(wait_for)                 # A's heavy half after B's previous one
-                    elif stage == sig:
+                    elif stage == 1:
                         ev_a.record(s0)
 
-                def hook_b(stage, ev_a=ev_a, ev_b=ev_b, free=first_only):
-                    if stage == 0 and not free:
+                def hook_b(stage, ev_a=ev_a, ev_b=ev_b):
+                    if stage == 0:
                         s1.wait_event(ev_a)                     # B's heavy half after A's
-                    elif stage == sig:
+                    elif stage == 1:
                         ev_b.record(s1)
 
                 evaluator.stage_hook = hook_a
@@ -393,7 +393,8 @@ def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator
     streams = [torch.cuda.Stream(device=dev) for _ in sessions]
     cur = torch.cuda.current_stream(dev)
     invariant = bool(getattr(evaluator, "batch_invariant", False))
-    paired = len(sessions) == 2 and hasattr(evaluator, "stage_hook")
+    import os
+    paired = len(sessions) == 2 and hasattr(evaluator, "stage_hook") and os.environ.get("C4_PAIR", "1") != "0"   # C4_PAIR=0: A/B knob
     graphs = []
     for s, st in zip(sessions, streams):
         st.wait_stream(cur)

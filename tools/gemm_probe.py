@@ -93,7 +93,7 @@ def main():
         b32 = b.float()
         y = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         row = {"hipblaslt": timeit(lambda: torch._addmm_activation(b, x, w.t(), use_gelu=False))}
-        for cfg in range(1, 11):
+        for cfg in (range(1, 17) if "PROBE_ALL" in os.environ else (4, 9, 10, 11, 17, 18, 19)):
             row[f"hip{cfg}"] = timeit(lambda: hip_linear(x, w, b32, cfg, y))
         fl = 2 * M * F * N
         out["alone_us"][f"N{N}"] = {k: round(v, 2) for k, v in row.items()}
@@ -126,6 +126,8 @@ def main():
 
     res = {}
     only = os.environ.get("PROBE_ONLY")
+    if only == "alone":
+        return
     combos = [(1, 1), (2, 2), (3, 3), (1, 4), (4, 4), (5, 5), (6, 6), (6, 4), (6, 10), (10, 10), (7, 7), (8, 8), (9, 9), (2, 9)]
     if only != "hip":
         res["hipblaslt"] = chain_pair(chain_factory("hipblaslt"))

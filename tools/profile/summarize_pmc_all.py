@@ -17,6 +17,7 @@ only = sys.argv[3:]
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"\[clone[^\]]*\]", "", name)
+    name = re.sub(r"^void ", "", name)
     return name.split("(")[0].strip()[:110]
 
 

@@ -16,7 +16,7 @@ torch.manual_seed(1337)
 net = InferenceNet(ConnectFourNet(ModelConfig(blocks, ch, 4, 2)), dev, dtype=torch.bfloat16)
 reqs = [c4a0_amd.GameMetadata(i, 0, 0) for i in range(n_games)]
 ref = None
-for k in (1, 2, 3, 4, 6, 8):
+for k in [int(x) for x in os.environ.get("SESSIONS", "1,2,3,4").split(",")]:
     st = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
