@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round-3 evidence for profiles/: run on the GPU box from the repo root (gpurun -- 'bash tools/profile/run_r03.sh').
+O=gpurun_out/r03p; mkdir -p $O; export TMPDIR=/tmp
+python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv; rm -rf $O/stats
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --independent-graphs > $O/bench_independent_graphs.json 2>/dev/null
+C4A0_GEMM=hipblaslt python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_hipblaslt.json 2>/dev/null
+python bench.py --whole-job > $O/whole_job.json 2> $O/whole_job.err
+python tools/tree_roofline.py --games 2048,4096,16384,65536,131072 > $O/tree_sweep.json 2> $O/tree_sweep.err
+bash tools/tower_ab.sh "2048 4096" > $O/tower.txt 2>&1
+python tools/tower_probe.py 64 8 2048 >> $O/tower.txt 2>&1
+python tools/callback_mode_rate.py 16384 > $O/callback_mode.txt 2>&1
+ls -la $O
