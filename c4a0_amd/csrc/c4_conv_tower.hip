@@ -96,9 +96,13 @@ struct TowerParams {
 //   * weights: C = 32 -- the workgroup fetches each layer's 18 KB ONCE, by global->LDS DMA into one of
 //     two stages a whole layer ahead, and every wavefront copies them LDS->registers at the start of
 //     the layer.  C = 64 -- requested from global memory after this layer's last epilogue.
-template <int C, int NB, bool kConv0, bool kSecond, int G_TILES, int MTW, bool kPrefetch, typename WF, typename Hook>
+//   * kLast (the tower's final layer): the epilogue stores to out[g][cell][C] in global memory instead of
+//     the LDS image -- no output pass, no barrier before it (8 bytes per lane, a cell's C channels are
+//     one 64- or 128-byte run written by 4 (lg) x MTW stores of neighbouring lanes).
+template <int C, int NB, bool kConv0, bool kSecond, bool kLast, int G_TILES, int MTW, bool kPrefetch, typename WF, typename Hook>
 __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4* __restrict__ dst, WF& wf,
-                                            const float* __restrict__ bias, int tile_lo, int m0, int lane, Hook&& after_last_tile) {
+                                            const float* __restrict__ bias, int tile_lo, int m0, int lane, Hook&& after_last_tile,
+                                            uint16_t* __restrict__ out = nullptr, uint32_t board0 = 0, uint32_t n_boards = 0) {
   using G = Geo<C, NB>;
   constexpr int kSteps = kConv0 ? 3 : 9 * G::KC;        // MFMA k-steps (= B fragments) per tile
   constexpr int NF = kPrefetch ? 2 : 1;                 // fragment sets
@@ -115,6 +119,7 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
   f32x4 acc[2][MTW];
   uint2 old[2][MTW];
   int e_slot[2], e_cell[2];     // of the tile whose accumulators sit in acc[.]: 16-byte slot index in a plane, padded cell
+  int e_board[2];               // ... and its board within the workgroup (kLast)
 
   auto tile_cell = [&](int g, int& cell) __attribute__((always_inline)) {   // plane-relative slot of this lane's cell of tile g
     const int tl = tile_lo + g;
@@ -150,6 +155,7 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
   };
   auto start_tile = [&](int g, int a) __attribute__((always_inline)) {     // geometry + residual of tile g, accumulators at the bias
     e_slot[a] = tile_cell(g, e_cell[a]);
+    e_board[a] = (tile_lo + g) / kTilesPerBoard;
 #pragma unroll
     for (int m = 0; m < MTW; m++) {
       acc[a][m] = bias4[m];
@@ -177,7 +183,15 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
         v[2] = o2 + fmaxf(v[2], 0.f); v[3] = o3 + fmaxf(v[3], 0.f);
       }
       const bf16x4 o = __builtin_convertvector(v, bf16x4);
-      if (valid) *out_ptr(e_slot[a], m) = __builtin_bit_cast(uint2, o);
+      if (kLast) {
+        // padded cell s: s - 1 = 8 (row + 1) + (col + 1)  ->  board cell 7 row + col
+        const int rc = e_cell[a] - 1, cell = 7 * ((rc >> 3) - 1) + (rc & 7) - 1;
+        const uint32_t gb = board0 + (uint32_t)e_board[a];
+        if (valid && gb < n_boards)
+          *reinterpret_cast<uint2*>(out + ((size_t)gb * 42 + cell) * C + 16 * (m0 + m) + 4 * lg) = __builtin_bit_cast(uint2, o);
+      } else if (valid) {
+        *out_ptr(e_slot[a], m) = __builtin_bit_cast(uint2, o);
+      }
     }
   };
 
@@ -265,19 +279,26 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   };
   if (G::kStageW) stage_layer_weights(1);
 
-  // ---- zero both images (halo cells stay zero for the whole kernel) ----
-  for (int i = tid; i < 2 * G::kBufSlots; i += NT) X[i] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
-
-  // ---- stage the input planes: channel group 0 of T holds {plane0, plane1, 0 x6} per cell ----
-  for (int i = tid; i < NB * 42; i += NT) {
+  // ---- the input planes are requested first (a global round trip), then both images are zeroed under
+  // that latency (halo cells stay zero for the whole kernel), then the planes go in: channel group 0 of T
+  // holds {plane0, plane1, 0 x6} per cell ----
+  constexpr int kIn = (NB * 42 + NT - 1) / NT;
+  uint32_t in_v[kIn];
+#pragma unroll
+  for (int j = 0; j < kIn; j++) {
+    const int i = tid + j * NT;
     const int b = i / 42, cell = i - b * 42;
     const uint32_t g = board0 + b;
-    if (g < p.n_boards) {
-      const uint32_t v0 = p.planes[(size_t)g * 84 + cell];
-      const uint32_t v1 = p.planes[(size_t)g * 84 + 42 + cell];
-      T[b * kBS + cell_slot(cell / 7, cell % 7)] = make_uint4(v0 | (v1 << 16), 0, 0, 0);
-    }
+    in_v[j] = 0;
+    if (i < NB * 42 && g < p.n_boards) in_v[j] = (uint32_t)p.planes[(size_t)g * 84 + cell] | ((uint32_t)p.planes[(size_t)g * 84 + 42 + cell] << 16);
+  }
+  for (int i = tid; i < 2 * G::kBufSlots; i += NT) X[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kIn; j++) {
+    const int i = tid + j * NT;
+    const int b = i / 42, cell = i - b * 42;
+    if (i < NB * 42) T[b * kBS + cell_slot(cell / 7, cell % 7)] = make_uint4(in_v[j], 0, 0, 0);
   }
   __syncthreads();
 
@@ -286,10 +307,11 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   static_assert(G::kTiles % kWaves == 0, "every wavefront owns the same number of cell tiles");
   constexpr int kTilesPerWave = G::kTiles / kWaves;
   constexpr bool kPrefetch = (C == 32);            // a second fragment set: 36 more registers at C = 32, 72 at C = 64 (too many)
+  constexpr bool kFuseOut = (C == 32);             // C = 64 has no registers left for the global address arithmetic (it would spill)
   const int tile_lo = (wave / MS) * kTilesPerWave;
 
   // conv0: input image (T) -> X
-  tower_layer<C, NB, true, false, kTilesPerWave, MTW, kPrefetch>(T, X, wf, p.bias, tile_lo, m0, lane, [&]() __attribute__((always_inline)) {
+  tower_layer<C, NB, true, false, false, kTilesPerWave, MTW, kPrefetch>(T, X, wf, p.bias, tile_lo, m0, lane, [&]() __attribute__((always_inline)) {
     if (!G::kStageW && n_layers >= 1) load_layer_weights(1);
   });
   if (G::kStageW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's share of the staged layer has landed
@@ -305,13 +327,18 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
     auto next_weights = [&]() __attribute__((always_inline)) {
       if (!G::kStageW && layer < n_layers) load_layer_weights(layer + 1);
     };
-    if (is_second) tower_layer<C, NB, false, true, kTilesPerWave, MTW, kPrefetch>(T, X, wf, p.bias + (size_t)layer * C, tile_lo, m0, lane, next_weights);
-    else tower_layer<C, NB, false, false, kTilesPerWave, MTW, kPrefetch>(X, T, wf, p.bias + (size_t)layer * C, tile_lo, m0, lane, next_weights);
+    if (kFuseOut && layer == n_layers) {   // the final layer (always the second conv of a block) stores the tower's output itself
+      tower_layer<C, NB, false, true, true, kTilesPerWave, MTW, kPrefetch>(T, X, wf, p.bias + (size_t)layer * C, tile_lo, m0, lane, next_weights,
+                                                                          p.out, board0, p.n_boards);
+      return;
+    }
+    if (is_second) tower_layer<C, NB, false, true, false, kTilesPerWave, MTW, kPrefetch>(T, X, wf, p.bias + (size_t)layer * C, tile_lo, m0, lane, next_weights);
+    else tower_layer<C, NB, false, false, false, kTilesPerWave, MTW, kPrefetch>(X, T, wf, p.bias + (size_t)layer * C, tile_lo, m0, lane, next_weights);
     if (G::kStageW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
-  // ---- X -> out[g][cell][C] ----
+  // ---- X -> out[g][cell][C] (C = 64, or no residual blocks: conv0's image is the output) ----
   for (int i = tid; i < NB * 42 * G::KG; i += NT) {
     const int kg = i % G::KG;
     const int bc = i / G::KG;

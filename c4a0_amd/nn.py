@@ -22,6 +22,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 N_COLS, N_ROWS = 7, 6
+import os as _os
+_ABLATE_HEAD_OUT = _os.environ.get("C4_ABLATE_HEAD_OUT") == "1"
 
 
 @dataclass
@@ -265,6 +267,8 @@ class InferenceNet:
             lp = out_logprobs if out_logprobs is not None else torch.empty((g, 7), dtype=torch.float32, device=self.device)
             q = out_q if out_q is not None else torch.empty((g, 2), dtype=torch.float32, device=self.device)
             assert p.stride(1) == 1 and v.stride(1) == 1
+            if _ABLATE_HEAD_OUT:   # timing experiment only: is the output kernel on the round's critical path?
+                return lp, q
             check(self._L.c4_head_out_bf16(C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()),
                                            C.c_void_p(self.pol_w[-1].data_ptr()), C.c_void_p(self.val_w[-1].data_ptr()),
                                            C.c_void_p(self.pol_b32.data_ptr()), C.c_void_p(self.val_b32.data_ptr()),
