@@ -721,6 +721,9 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
           finished = true;
         }
       }
+      // Did any game of this wavefront move in this launch?  Asked here, where every game that entered the
+      // trip is still in it (a wavefront's 8 games run in lock-step: one game's extra work is everybody's).
+      const bool wave_moved = __ballot(c_moves != 0) != 0ull;
       if (err) break;
 
       C4_STAMP_TRIP1(12, root_n);
@@ -760,7 +763,14 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
       // a terminal leaf needs no evaluator, nor does one whose evaluation is in the cache: run that
       // simulation now, while trips remain
       if (sim + 1 < max_sims) {
-        bool again = term != 0;
+        // A launch lasts as long as its slowest wavefront.  A wavefront with a MOVING game has already
+        // paid the longest path of the step (root policy, temperature, sampling, sample record, re-root:
+        // +1.7-2.7 us), and a second, terminal-leaf simulation costs +2.0 us more: such a wavefront leaves
+        // its terminal leaves to the next launch (an evaluator row is then wasted on them, as the reference
+        // wastes one on every terminal leaf, mcts.rs:92-98; samples are identical either way).  Measured:
+        // 10.36 -> 9.61 us per 2 048-game launch alone, 11.5 -> 10.6 beside the evaluator
+        // (profiles/r03_step_second_trip_ab.txt).  The evaluation-cache build keeps all its trips.
+        bool again = term != 0 && (CACHE || !wave_moved);
         if (CACHE && !again) {
           c_probes += 1;
           again = cache_lookup(p.cache, p.cache_mask, leaf_mask, leaf_value, cur_logit, cur_qp, cur_qn, sub, gbase);
