@@ -465,6 +465,7 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     case 17: return launch_gemm32<256, 192, 2, 4, 4>(p, st, device);   // 8 wavefronts (128 x 48), 32-deep k-tiles, 4-deep ring, 112 KB
     case 18: return launch_gemm32<256, 192, 2, 4, 3>(p, st, device);   // ... 3-deep ring, 84 KB
     case 19: return launch_gemm32<256, 192, 4, 2, 4>(p, st, device);   // 8 wavefronts (64 x 96), 4-deep ring
+    case 20: return launch_gemm<128, 192, 2, 4, 2, 2>(p, st, device);  // 8 wavefronts (64 x 48), 2-deep ring, 80 KB: two workgroups per CU
     default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
   }
 }

@@ -254,6 +254,8 @@ class InferenceNet:
         else:
             p = v = x
             pol_rest, val_rest = list(zip(self.pol_w[:-1], self.pol_b[:-1])), list(zip(self.val_w[:-1], self.val_b[:-1]))
+            if hook is not None:   # no merged first layer (a head without hidden layers): the heavy half ends with the tower
+                hook(1)
         for w, b in pol_rest:
             p = self._linear_relu(p, w, b)
         for w, b in val_rest:

@@ -4,6 +4,11 @@ O=gpurun_out/r03p; mkdir -p $O; export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv; rm -rf $O/stats
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --rounds-per-step 64 --preroll 640 --instrumented-steps 300 --no-cpu-baseline > $O/pmc_$c.json 2> $O/pmc_$c.err
+  python tools/profile/summarize_pmc.py $O/pmc_$c c4_step_kernel 800 > $O/traffic_$c.json
+  rm -rf $O/pmc_$c
+done
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --independent-graphs > $O/bench_independent_graphs.json 2>/dev/null
 C4A0_GEMM=hipblaslt python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_hipblaslt.json 2>/dev/null
 python bench.py --whole-job > $O/whole_job.json 2> $O/whole_job.err

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Refresh profiles/step_kernel_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the
+bench command, summarised by tools/profile/summarize_pmc.py, and the bench line of one of those runs.
+    python tools/profile/update_traffic.py <traffic_FETCH_SIZE.json> <traffic_WRITE_SIZE.json> <pmc bench json> <label>"""
+import json
+import os
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+path = os.path.join(root, "profiles", "step_kernel_traffic.json")
+old = json.load(open(path))
+f, w = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+bench = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+label = sys.argv[4]
+hist = old.get("history", {})
+hist[f"before: {old.get('note', '')[:80]}"] = {k: old[k] for k in ("FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch", "hbm_bytes_per_launch_raw", "hbm_bytes_per_launch") if k in old}
+fk, wk = f["FETCH_SIZE"], w["WRITE_SIZE"]
+alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+raw, corr = (fk + wk) * 1024, (2 * fk + wk) * 1024
+new = dict(old)
+new.update({"launches_averaged": int(min(f["dispatches_averaged"], w["dispatches_averaged"])), "FETCH_SIZE_KB_per_launch": round(fk, 1),
+            "WRITE_SIZE_KB_per_launch": round(wk, 1), "hbm_bytes_per_launch_raw": int(raw), "hbm_bytes_per_launch": int(corr),
+            "algorithmic_bytes_per_launch": int(alg), "ratio_raw": round(raw / alg, 2), "ratio_fetch_doubled": round(corr / alg, 2),
+            "history": hist, "note": label,
+            "command": old["command"].replace("tools/profile/run_r02.sh", "tools/profile/run_r03.sh")})
+json.dump(new, open(path, "w"), indent=1)
+print(json.dumps({k: new[k] for k in ("FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "ratio_raw", "ratio_fetch_doubled")}))
