@@ -256,8 +256,10 @@ class InferenceNet:
             pol_rest, val_rest = list(zip(self.pol_w[:-1], self.pol_b[:-1])), list(zip(self.val_w[:-1], self.val_b[:-1]))
             if hook is not None:   # no merged first layer (a head without hidden layers): the heavy half ends with the tower
                 hook(1)
-        for w, b in pol_rest:
+        for i, (w, b) in enumerate(pol_rest):
             p = self._linear_relu(p, w, b)
+            if hook is not None:
+                hook(3 + i)      # experiment knob of session.capture_pair (C4_PAIR_OFFSET): after each narrow policy layer
         for w, b in val_rest:
             v = self._linear_relu(v, w, b)
         if self.hip_tower:

@@ -347,16 +347,27 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
             b.bind(s1)
             s1.wait_stream(s0)                                  # fork: s1 joins the capture
             ev_b_prev = None
-            for _ in range(steps_per_graph):
+            import os
+            offset_stage = int(os.environ.get("C4_PAIR_OFFSET", "0"))   # experiment: B starts once after this stage of A's first round, then both run free
+            for r in range(steps_per_graph):
                 ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
+                free = offset_stage != 0
 
-                def hook_a(stage, ev_a=ev_a, wait_for=ev_b_prev):
+                def hook_a(stage, ev_a=ev_a, wait_for=ev_b_prev, free=free, r=r):
+                    if free:
+                        if r == 0 and stage == offset_stage:
+                            ev_a.record(s0)
+                        return
                     if stage == 0 and wait_for is not None:
                         s0.wait_event(wait_for)                 # A's heavy half after B's previous one
                     elif stage == 1:
                         ev_a.record(s0)
 
-                def hook_b(stage, ev_a=ev_a, ev_b=ev_b):
+                def hook_b(stage, ev_a=ev_a, ev_b=ev_b, free=free, r=r):
+                    if free:
+                        if r == 0 and stage == 0:
+                            s1.wait_event(ev_a)
+                        return
                     if stage == 0:
                         s1.wait_event(ev_a)                     # B's heavy half after A's
                     elif stage == 1:
