@@ -259,7 +259,7 @@ class InferenceNet:
         for i, (w, b) in enumerate(pol_rest):
             p = self._linear_relu(p, w, b)
             if hook is not None:
-                hook(3 + i)      # experiment knob of session.capture_pair (C4_PAIR_OFFSET): after each narrow policy layer
+                hook(3 + i)      # after each narrow policy layer (session.capture_pair's phase experiments, C4_PAIR_OFFSET)
         for w, b in val_rest:
             v = self._linear_relu(v, w, b)
         if self.hip_tower:

@@ -312,15 +312,16 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
     contention between them happens to lock: measured on MI355X the same binary runs at 22.5 k or 25.7 k
     games/s (and a faster tower moved it to 23.1 k or 27.5 k) depending on that phase -- in phase, both
     sessions' latency-bound kernels (head outputs, step kernel) leave the chip idle together.  Here the
-    phase is part of the graph: session B's [tower, first hidden layer] may start only when session A's
-    has finished, and A's next [tower, first layer] only when B's has -- the two heavy halves strictly
-    alternate, each running beside the OTHER session's [narrow layers, head outputs, step kernel].
-    Cross-stream events recorded and awaited during capture become edges of the graph; nothing else
-    changes (same kernels, same per-session order, same samples).  Where exactly the hand-over points sit
-    (after the tower, after the first layer, only once per graph) made no measurable difference
-    (25.2-25.3 k games/s for all of them on one box; two free-running graphs: 26.0 k in their good phase,
-    22.7-23.2 k in their bad one, one run in three): what the single graph buys is that the result no longer
-    depends on a coin toss at start-up.
+    phase is part of the graph: in the first round of every replay session B's [tower, first hidden layer]
+    starts only when session A's has finished (a cross-stream event recorded and awaited during capture: an
+    edge of the graph), i.e. B runs half a round behind A, each session's heavy half beside the OTHER's
+    [narrow layers, head outputs, step kernel]; for the rest of the replay the two streams run free from
+    that phase, and the join at the graph's end re-aligns them.  Nothing else changes (same kernels, same
+    per-session order, same samples).  Measured on one box (profiles/r03_pairing.txt): this 25.7 k games/s
+    every time; a hand-over in EVERY round (C4_PAIR_STRICT=1) 25.4-25.5 k; starting B after A's third GEMM
+    instead 22.8 k (the bad phase, reproduced on purpose); two free-running graphs 26.1-26.2 k in four runs
+    out of five and 24.3 k in the fifth (22.7 k on other boxes).  What the single graph buys is that the
+    result no longer depends on a coin toss at start-up, for 1.6 % of the lucky case.
 
     `evaluator` must be a c4a0_amd.nn.InferenceNet (its `stage_hook` marks the two points).  The graph
     is replayed on streams[0]; both sessions stay bound to their streams."""
@@ -348,10 +349,11 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
             s1.wait_stream(s0)                                  # fork: s1 joins the capture
             ev_b_prev = None
             import os
-            offset_stage = int(os.environ.get("C4_PAIR_OFFSET", "0"))   # experiment: B starts once after this stage of A's first round, then both run free
+            strict = os.environ.get("C4_PAIR_STRICT") == "1"    # A/B knob: hand-over in EVERY round instead of once per graph
+            offset_stage = int(os.environ.get("C4_PAIR_OFFSET", "1"))   # B starts when this stage of A's first round is done (1 = first hidden layer)
             for r in range(steps_per_graph):
                 ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
-                free = offset_stage != 0
+                free = not strict
 
                 def hook_a(stage, ev_a=ev_a, wait_for=ev_b_prev, free=free, r=r):
                     if free:
