@@ -26,6 +26,7 @@
 //     tiles and split the output channels, so a wave holds half of a layer's weights (144 registers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <string>
@@ -482,7 +483,10 @@ __global__ __launch_bounds__(256) void c4_head_out_kernel(const uint4* __restric
 // every wavefront requests all of its operands before the first MFMA (one memory round trip), and
 // the partial tiles meet in LDS.  No cross-lane reduction per output, 16-byte loads only.
 constexpr int kHeadWaves = 6, kHeadSteps = 7;
-__global__ __launch_bounds__(64 * kHeadWaves) void c4_head_out_mfma_kernel(
+// kRows = boards per workgroup: 16 (every row of the MFMA tile a board) or 8 (small launches: twice the workgroups, so
+// that a 2 048-board launch uses every CU and each CU pulls half the activations; rows 8..15 repeat rows 0..7).
+template <int kRows>
+__global__ __launch_bounds__(64 * kHeadWaves, 1) void c4_head_out_mfma_kernel(
     const uint4* __restrict__ hp, const uint4* __restrict__ hv, const uint4* __restrict__ wp, const uint4* __restrict__ wv,
     const float* __restrict__ bp, const float* __restrict__ bv, uint32_t n_boards, uint32_t f8, uint32_t sp8, uint32_t sv8,
     float* __restrict__ logprobs, float* __restrict__ q) {
@@ -490,14 +494,21 @@ __global__ __launch_bounds__(64 * kHeadWaves) void c4_head_out_mfma_kernel(
   __shared__ float tile[2][16][17];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t row = lane & 15, kq = lane >> 4;
-  const uint32_t g0 = blockIdx.x * 16;
-  const uint32_t g = (g0 + row < n_boards) ? g0 + row : n_boards - 1;     // tail rows recompute the last board (never stored)
+  const uint32_t g0 = blockIdx.x * kRows;
+  const uint32_t gr = g0 + (row & (kRows - 1));
+  const uint32_t g = gr < n_boards ? gr : n_boards - 1;                   // tail rows recompute the last board (never stored)
   const uint4* xp = hp + (size_t)g * sp8 + kq;
   const uint4* xv = hv + (size_t)g * sv8 + kq;
   const uint4* wpl = wp + (size_t)(row < 7 ? row : 0) * f8 + kq;           // B column = output `row`
   const uint4* wvl = wv + (size_t)(row < 2 ? row : 0) * f8 + kq;
-  const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
   f32x4 accp = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
+#ifdef C4_PHASE_STAMPS   // diagnostic build: where does a workgroup of this kernel spend its time?
+  unsigned long long hs[6];
+#define C4_HSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); hs[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define C4_HSTAMP(i) do { } while (0)
+#endif
+  C4_HSTAMP(0);
   const uint32_t n_iter = f8 / (4 * kHeadSteps * kHeadWaves);
   for (uint32_t it = 0; it < n_iter; it++) {
     const uint32_t s0 = (it * kHeadWaves + wave) * kHeadSteps;           // first k-step (of 32 features) of this wavefront
@@ -506,18 +517,30 @@ __global__ __launch_bounds__(64 * kHeadWaves) void c4_head_out_mfma_kernel(
     for (int s = 0; s < kHeadSteps; s++) {
       a_p[s] = xp[4 * (s0 + s)];
       a_v[s] = xv[4 * (s0 + s)];
-      b_p[s] = row < 7 ? wpl[4 * (s0 + s)] : zero;
-      b_v[s] = row < 2 ? wvl[4 * (s0 + s)] : zero;
+      b_p[s] = wpl[4 * (s0 + s)];      // every lane loads (lanes beyond the 7 / 2 outputs re-read row 0) and is masked AFTERWARDS:
+      b_v[s] = wvl[4 * (s0 + s)];      // a "load or zero" select makes hipcc branch around each load and drain vmcnt per element
     }
+    // (round 3: with the select in the loop above the 28 requests of a wavefront went out two at a time, each pair
+    // waited for -- twelve serial memory round trips, 8.2 of the kernel's 8.6 us.  Now one round trip.)
+    __builtin_amdgcn_sched_barrier(0);   // ... and the scheduler must not re-interleave loads and MFMAs to save registers
+    const uint32_t mp = row < 7 ? 0xFFFFFFFFu : 0u, mv = row < 2 ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int s = 0; s < kHeadSteps; s++) {
+      b_p[s].x &= mp; b_p[s].y &= mp; b_p[s].z &= mp; b_p[s].w &= mp;
+      b_v[s].x &= mv; b_v[s].y &= mv; b_v[s].z &= mv; b_v[s].w &= mv;
+    }
+    C4_HSTAMP(1);
 #pragma unroll
     for (int s = 0; s < kHeadSteps; s++) {
       accp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_p[s]), __builtin_bit_cast(bf16x8, b_p[s]), accp, 0, 0, 0);
       accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_v[s]), __builtin_bit_cast(bf16x8, b_v[s]), accv, 0, 0, 0);
     }
   }
+  C4_HSTAMP(2);
   part[wave][0][lane] = accp;
   part[wave][1][lane] = accv;
   __syncthreads();
+  C4_HSTAMP(3);
   if (wave < 2) {
     // wavefront 0 finishes the policy tile, wavefront 1 the value tile: lane holds output column
     // `row` of boards 4 kq .. 4 kq + 3
@@ -529,7 +552,8 @@ __global__ __launch_bounds__(64 * kHeadWaves) void c4_head_out_mfma_kernel(
     for (int r = 0; r < 4; r++) tile[wave][4 * kq + r][row] = sum[r] + bias;
   }
   __syncthreads();
-  if (threadIdx.x < 16) {
+  C4_HSTAMP(4);
+  if (threadIdx.x < kRows) {
     const uint32_t b = threadIdx.x, gb = g0 + b;
     if (gb < n_boards) {
       float v[9];
@@ -550,6 +574,12 @@ __global__ __launch_bounds__(64 * kHeadWaves) void c4_head_out_mfma_kernel(
       q[(size_t)gb * 2 + 1] = tanhf(v[8]);
     }
   }
+#ifdef C4_PHASE_STAMPS
+  C4_HSTAMP(5);
+  if (threadIdx.x == 0 && (blockIdx.x == 3 || blockIdx.x == 77))
+    printf("head_out wg %u: loads %llu  mfma %llu  partials+barrier %llu  sum+barrier %llu  softmax/tanh+stores %llu  (10 ns ticks)\n", blockIdx.x,
+           hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4]);
+#endif
 }
 
 }  // namespace
@@ -567,9 +597,11 @@ extern "C" int c4_head_out_bf16(const void* hidden_policy_dev, const void* hidde
   c4host::DeviceGuard guard(device);
   if (guard.error() != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_head_out_bf16: hipSetDevice: ") + hipGetErrorString(guard.error()));
   if ((features / 8) % (4 * kHeadSteps * kHeadWaves) == 0) {
-    c4_head_out_mfma_kernel<<<dim3((n_boards + 15) / 16), dim3(64 * kHeadWaves), 0, (hipStream_t)stream>>>(
-        (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
-        b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
+    // (8 boards per workgroup -- twice the workgroups for launches that leave half the CUs without one -- was
+    // measured too: 6.1 vs 6.0 us at 2 048 boards, no gain; the template parameter stays for the next experiment)
+    c4_head_out_mfma_kernel<16><<<dim3((n_boards + 15) / 16), dim3(64 * kHeadWaves), 0, (hipStream_t)stream>>>(
+          (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev, (const uint4*)w_policy_dev, (const uint4*)w_value_dev,
+          b_policy_dev, b_value_dev, n_boards, features / 8, policy_row_stride / 8, value_row_stride / 8, logprobs_dev, q_dev);
   } else {
     constexpr int kBoardsPerWave = 2;   // other feature counts: dot-product form (measured best of 1 / 2 / 4 boards per wavefront)
     c4_head_out_kernel<kBoardsPerWave><<<dim3((n_boards + 4 * kBoardsPerWave - 1) / (4 * kBoardsPerWave)), dim3(256), 0, (hipStream_t)stream>>>(
