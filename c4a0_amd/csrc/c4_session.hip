@@ -503,6 +503,10 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
   const uint4 hot = reinterpret_cast<const uint4*>(st)[sub];
   const float nn_logit = p.logprobs[(size_t)gs * 7 + (sub < 7 ? sub : 6)];
   const float nn_q = p.q[(size_t)gs * 2 + (sub & 1)];
+  // ... and they must LEAVE together: without this fence hipcc sinks the two evaluator loads into the
+  // `if (active)` below, i.e. behind the wait for the state line -- a second, serial memory round trip (plus the
+  // scalar loads of the two pointers) at the head of every wavefront's chain (round 3, found in the ISA).
+  __builtin_amdgcn_sched_barrier(0);
   // header words to every lane of the group (lane 3: state, arena, root ref, rng word)
   const uint32_t state0 = shfl_u32(hot.x, gbase + 3);
   bool active = (g < p.n_slots) && (slot_status(state0) == kActive);
