@@ -48,12 +48,13 @@ class _CallbackEvaluator:
     (self_play.rs:196-237): per step, the unique (model, leaf position) pairs of all resident
     games are evaluated in chunks of at most max_nn_batch_size, one model per call.
 
-    The bookkeeping runs on the device: the session writes one int64 key per slot
-    (c4_session_leaf_keys), a device sort finds the unique positions and the slot -> unique-row map,
-    only the unique rows of the evaluator input travel to the host (pinned, one copy) and only the
-    unique answers travel back; the answers are fanned out to the slots by a device gather.  The
-    callback sees exactly what the reference's sees: float32 [B, 2, 6, 7], unique positions,
-    B <= max_nn_batch_size, one model per call."""
+    The bookkeeping runs on the device (c4_session_unique_leaves: three small launches): the slots
+    meet in a hash table, the representatives are ranked in slot order and write their rows of the
+    evaluator input straight into a pinned host array -- one PCIe crossing, no staging copy, and
+    the host learns the batch size from one pinned word after one stream synchronisation.  The
+    answers go back the same way (c4_session_scatter_outputs reads the pinned answer rows and fans
+    them out to every slot that asked).  The callback sees exactly what the reference's sees:
+    float32 [B, 2, 6, 7], unique positions, B <= max_nn_batch_size, one model per call."""
 
     def __init__(self, session: DeviceSession, cb: Callable, max_nn_batch_size: int, p0: np.ndarray, p1: np.ndarray):
         import ctypes as C
@@ -62,75 +63,55 @@ class _CallbackEvaluator:
         self._C, self._check = C, check
         self.s, self.cb, self.cap = session, cb, max(1, int(max_nn_batch_size))
         dev, g = session.device, session.n_slots
-        self.keys = torch.zeros(g, dtype=torch.int64, device=dev)
         self.models_used = np.unique(np.concatenate([p0, p1]))
         self.multi = self.models_used.size > 1
         self.slot_models = session.bind_leaf_models() if self.multi else None   # the step kernel publishes mcts.rs:70-76 per slot
-        self.arange = torch.arange(g, dtype=torch.int64, device=dev)
-        # pinned staging of the unique answers on their way back (the input batches are fresh pinned arrays, see __call__)
+        self.inverse = torch.zeros(g, dtype=torch.int32, device=dev)            # slot -> row of the batch
+        self.h_count = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.h_models = torch.zeros(g, dtype=torch.int64).pin_memory() if self.multi else None
+        # pinned staging of the answers on their way back (the input batches are fresh pinned arrays, see __call__)
         self.h_out = torch.empty((g, 9), dtype=torch.float32).pin_memory()
-        self.d_out = torch.empty((g, 9), dtype=torch.float32, device=dev)
         self.nn_positions = 0
-        if session.planes.dtype != torch.float32:
-            raise ValueError("the numpy callback takes float32 planes")
 
     def __call__(self, _planes: torch.Tensor):
         s, C = self.s, self._C
-        self._check(s.L.c4_session_leaf_keys(s._h, C.c_void_p(self.keys.data_ptr())))
-        if self.multi:   # group by model first: rows sort as (idle?, model, position)
-            # idle slots are marked by a column of their own, not by a model id: every 64-bit id is a valid model
-            # (ids >= 2^63 are negative as int64 bit patterns; they still sort into one run per model)
-            idle = self.keys < 0
-            zero = torch.zeros_like(self.keys)
-            rows = torch.stack([idle.to(torch.int64), torch.where(idle, zero, self.slot_models), torch.where(idle, zero - 1, self.keys)], dim=1)
-            uniq, inv = torch.unique(rows, dim=0, return_inverse=True)
-            u_models, u_keys = uniq[:, 1], uniq[:, 2]
-        else:
-            u_keys, inv = torch.unique(self.keys, return_inverse=True)
-            u_models = None
-        n_u = u_keys.shape[0]
-        # any slot holding a unique position stands for it: take its row of the evaluator input
-        first = torch.empty(n_u, dtype=torch.int64, device=s.device).scatter_(0, inv, self.arange)
+        g = s.n_slots
         # A FRESH pinned array per step (PyTorch's caching host allocator: no system call after warm-up), as the
         # reference hands its callback a new array it owns (pybridge.rs:220 into_pyarray): a callback that keeps x
-        # keeps this block alive, nothing it was given is ever overwritten.  Still one PCIe transfer.
-        h_planes = torch.empty((n_u, 2, 6, 7), dtype=torch.float32, pin_memory=True)
-        h_planes.copy_(s.planes.index_select(0, first), non_blocking=True)
-        keys_h = u_keys.cpu().numpy()              # synchronises: the rows above have landed too
-        live = keys_h >= 0                         # idle slots share the key -1
-        if live.any():
-            models_h = u_models.cpu().numpy() if self.multi else None
-            planes_np, out_np = h_planes.numpy(), self.h_out.numpy()
-            # runs of one model (rows are sorted by model, then position), without the idle row
-            if self.multi:
-                cuts = np.flatnonzero(np.diff(models_h)) + 1
-                groups = [(int(a), int(b)) for a, b in zip(np.concatenate([[0], cuts]), np.concatenate([cuts, [n_u]]))]
-            else:
-                groups = [(0, n_u)]
-            for lo, hi_model in groups:
-                while lo < hi_model and not live[lo]:          # single-model mode: the idle key -1 sorts first
-                    lo += 1
-                while hi_model > lo and not live[hi_model - 1]:  # multi-model mode: the idle row sorts last
-                    hi_model -= 1
-                if lo >= hi_model:
-                    continue
-                mid = (int(models_h[lo]) & ((1 << 64) - 1)) if self.multi else int(self.models_used[0])
-                for i in range(lo, hi_model, self.cap):
-                    j = min(i + self.cap, hi_model)
-                    out = self.cb(mid, planes_np[i:j])
-                    if not (isinstance(out, (tuple, list)) and len(out) == 3):
-                        raise TypeError("py_eval_pos_cb must return (policy_logprobs, q_penalty, q_no_penalty)")
-                    lp, qp, qn = (np.asarray(a) for a in out)
-                    for name, a, shape in (("policy", lp, (j - i, 7)), ("q_penalty", qp, (j - i,)), ("q_no_penalty", qn, (j - i,))):
-                        # pybridge.rs:175-188: contiguous float32 arrays of the batch's shape
-                        if a.dtype != np.float32 or a.shape != shape or not a.flags["C_CONTIGUOUS"]:
-                            raise TypeError(f"py_eval_pos_cb: {name} must be C-contiguous float32 of shape {shape}, got {a.dtype} {a.shape}")
-                    out_np[i:j, :7], out_np[i:j, 7], out_np[i:j, 8] = lp, qp, qn
-                    self.nn_positions += j - i
-            self.d_out[:n_u].copy_(self.h_out[:n_u], non_blocking=True)
-            fan = self.d_out.index_select(0, inv)            # unique answers -> every slot that asked
-            s.logprobs.copy_(fan[:, :7])
-            s.q.copy_(fan[:, 7:9])
+        # keeps this block alive, nothing it was given is ever overwritten.
+        h_planes = torch.empty((g, 2, 6, 7), dtype=torch.float32, pin_memory=True)
+        self._check(s.L.c4_session_unique_leaves(s._h, C.c_void_p(self.inverse.data_ptr()), C.c_void_p(h_planes.data_ptr()),
+                                                 C.c_void_p(self.h_models.data_ptr()) if self.multi else None,
+                                                 C.c_void_p(self.h_count.data_ptr())))
+        s._bound_stream.synchronize()              # the batch and its size have landed in host memory
+        n_u = int(self.h_count[0])
+        if n_u == 0:                               # every resident game has finished
+            return s.logprobs, s.q
+        planes_np, out_np = h_planes.numpy()[:n_u], self.h_out.numpy()
+        if self.multi:
+            # one model per call (self_play.rs:203-215), ascending ids; ids are 64-bit patterns (>= 2^63 negative here)
+            models_h = self.h_models.numpy()[:n_u]
+            groups = [(int(m) & ((1 << 64) - 1), np.flatnonzero(models_h == m)) for m in np.unique(models_h.view(np.uint64)).view(np.int64)]
+        else:
+            groups = [(int(self.models_used[0]), None)]
+        for mid, rows in groups:
+            n_rows = n_u if rows is None else rows.size
+            for i in range(0, n_rows, self.cap):
+                j = min(i + self.cap, n_rows)
+                sel = slice(i, j) if rows is None else rows[i:j]
+                out = self.cb(mid, planes_np[sel])   # a view of the fresh array, or (several models) a gathered copy
+                if not (isinstance(out, (tuple, list)) and len(out) == 3):
+                    raise TypeError("py_eval_pos_cb must return (policy_logprobs, q_penalty, q_no_penalty)")
+                lp, qp, qn = (np.asarray(a) for a in out)
+                for name, a, shape in (("policy", lp, (j - i, 7)), ("q_penalty", qp, (j - i,)), ("q_no_penalty", qn, (j - i,))):
+                    # pybridge.rs:175-188: contiguous float32 arrays of the batch's shape
+                    if a.dtype != np.float32 or a.shape != shape or not a.flags["C_CONTIGUOUS"]:
+                        raise TypeError(f"py_eval_pos_cb: {name} must be C-contiguous float32 of shape {shape}, got {a.dtype} {a.shape}")
+                out_np[sel, :7], out_np[sel, 7], out_np[sel, 8] = lp, qp, qn
+                self.nn_positions += j - i
+        # h_out is read by the kernel on the session's stream; the next write to it happens after the next step's
+        # synchronisation above, which that kernel precedes
+        self._check(s.L.c4_session_scatter_outputs(s._h, C.c_void_p(self.inverse.data_ptr()), C.c_void_p(self.h_out.data_ptr()), n_u))
         return s.logprobs, s.q
 
 

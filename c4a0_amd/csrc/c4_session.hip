@@ -1011,18 +1011,106 @@ __global__ __launch_bounds__(1024) void k_sample_offsets(const uint32_t* counts,
 // (model, leaf position) pairs).  A position is its `value` bits (42) plus the 7 column heights
 // (3 bits each: the stones of a column stack from the bottom, so the heights determine `mask`):
 // 63 bits, one non-negative int64 per resident game; idle slots get -1.
+C4_DEV long long leaf_key_of(const Slot* st) {
+  if (slot_status(st->state) != kActive) return -1;
+  const uint64_t m = st->leaf_mask, v = st->leaf_value;
+  uint64_t heights = 0;
+  for (uint32_t c = 0; c < 7; c++) heights |= (uint64_t)__popcll(m & (c4::kCol0 << c)) << (3 * c);
+  return (long long)(v | (heights << 42));
+}
+
 __global__ void k_leaf_keys(const Slot* slots, uint32_t n_slots, long long* keys) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n_slots) keys[g] = leaf_key_of(slots + g);
+}
+
+// ---- the callback evaluator's batch on the device (NNThread::loop_once, self_play.rs:203-208) ----
+// The reference collects the waiting leaves in a HashSet<(model, Pos)> and evaluates each pair once.
+// Three small launches do the same for all resident games: (1) every slot enters an open-addressed
+// table of SLOT INDICES (a cell's pair is its slot's pair; slots with one pair meet in one cell and
+// keep the lowest index), (2) one workgroup ranks the representatives in slot order -- the batch's
+// row order depends on nothing but the games -- and maps every slot to its row, (3) the
+// representatives write their rows of the evaluator input ([2, 6, 7] float32, c4r.rs:378-392)
+// wherever the caller asked: normally pinned host memory, so the batch crosses PCIe once, written
+// by the kernel, and the host learns its size from one pinned word.
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+constexpr uint32_t kRepFlag = 0x80000000u;
+
+__global__ void k_unique_insert(const Slot* slots, const uint64_t* leaf_models, uint32_t n_slots, uint32_t* tab,
+                                uint32_t tab_mask, uint32_t* cell) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_slots) return;
-  const Slot* st = slots + g;
-  long long key = -1;
-  if (slot_status(st->state) == kActive) {
-    const uint64_t m = st->leaf_mask, v = st->leaf_value;
-    uint64_t heights = 0;
-    for (uint32_t c = 0; c < 7; c++) heights |= (uint64_t)__popcll(m & (c4::kCol0 << c)) << (3 * c);
-    key = (long long)(v | (heights << 42));
+  const long long key = leaf_key_of(slots + g);
+  if (key < 0) { cell[g] = kNoSlot; return; }
+  const uint64_t model = leaf_models ? leaf_models[g] : 0ull;
+  uint64_t x = ((uint64_t)key ^ (model * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;   // any mix does: only the
+  uint32_t h = (uint32_t)(x >> 32) & tab_mask;                                              // probe order depends on it
+  for (;;) {
+    const uint32_t cur = atomicCAS(&tab[h], kNoSlot, g);
+    if (cur == kNoSlot) break;                                     // first of its pair: this cell is the pair's
+    if (leaf_key_of(slots + cur) == key && (!leaf_models || leaf_models[cur] == model)) {
+      atomicMin(&tab[h], g);                                       // same pair: the lowest slot represents it
+      break;
+    }
+    h = (h + 1) & tab_mask;                                        // another pair's cell (cells never change pair)
   }
-  keys[g] = key;
+  cell[g] = h;
+}
+
+__global__ __launch_bounds__(1024) void k_unique_rank(const uint32_t* tab, const uint32_t* cell, uint32_t n_slots,
+                                                      uint32_t* row_of, uint32_t* inverse, uint32_t* n_unique_dev,
+                                                      uint32_t* n_unique_out) {
+  __shared__ uint32_t wave_sum[16];
+  __shared__ uint32_t carry;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_slots; base += 1024) {
+    const uint32_t g = base + tid;
+    const bool rep = g < n_slots && cell[g] != kNoSlot && tab[cell[g]] == g;
+    const unsigned long long b = __ballot(rep);
+    if (lane == 0) wave_sum[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t before = carry;
+    for (uint32_t w = 0; w < wave; w++) before += wave_sum[w];
+    if (g < n_slots) row_of[g] = rep ? ((before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))) | kRepFlag) : 0u;
+    __syncthreads();
+    if (tid == 1023) carry = before + (uint32_t)__popcll(b);
+    __syncthreads();
+  }
+  __threadfence_block();
+  for (uint32_t g = tid; g < n_slots; g += 1024)
+    inverse[g] = cell[g] == kNoSlot ? kNoSlot : (row_of[tab[cell[g]]] & ~kRepFlag);
+  if (tid == 0) { *n_unique_dev = carry; *n_unique_out = carry; }
+}
+
+// one wavefront per slot; also hands the table back empty (nothing reads it here)
+__global__ __launch_bounds__(256) void k_unique_emit(const Slot* slots, const uint64_t* leaf_models, uint32_t n_slots,
+                                                     uint32_t* tab, const uint32_t* cell, const uint32_t* row_of,
+                                                     float* rows_out, uint64_t* models_out) {
+  const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= n_slots) return;
+  const uint32_t c = cell[g];
+  if (c == kNoSlot) return;
+  if (lane == 0) tab[c] = kNoSlot;
+  const uint32_t r = row_of[g];
+  if (!(r & kRepFlag)) return;
+  const uint32_t row = r & ~kRepFlag;
+  const uint64_t m = slots[g].leaf_mask, v = slots[g].leaf_value;
+  for (uint32_t e = lane; e < C4_PLANES_LEN; e += 64) rows_out[(size_t)row * C4_PLANES_LEN + e] = c4::plane_bit(m, v, e) ? 1.0f : 0.0f;
+  if (models_out && lane == 0) models_out[row] = leaf_models ? leaf_models[g] : 0ull;
+}
+
+// the evaluator's answers back to every slot that asked: answers[row] = 7 log-probabilities, q_penalty, q_no_penalty
+__global__ void k_unique_scatter(const uint32_t* inverse, const float* answers, uint32_t n_slots, uint32_t n_unique,
+                                 float* logprobs, float* q) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g = i / 9, e = i % 9;
+  if (g >= n_slots) return;
+  const uint32_t row = inverse[g];
+  if (row >= n_unique) return;                                     // idle slot
+  const float a = answers[(size_t)row * 9 + e];
+  if (e < 7) logprobs[(size_t)g * 7 + e] = a; else q[(size_t)g * 2 + (e - 7)] = a;
 }
 
 // K6: pack finished games' records contiguously (one wavefront per game, 4 records per pass)
@@ -1087,6 +1175,12 @@ struct c4_session {
   float* ln_tab_dev = nullptr;                 // ln(visit count) table of select (Params::ln_tab)
   unsigned long long* offsets_dev = nullptr;   // pack_samples: [n_games] record offsets + [1] total, sized by set_games
   unsigned long long* total_host = nullptr;    // pinned
+  // c4_session_unique_leaves scratch (first use): table of slot indices, each slot's cell, its row, the count
+  uint32_t* uniq_tab = nullptr;
+  uint32_t uniq_tab_mask = 0;
+  uint32_t* uniq_cell = nullptr;
+  uint32_t* uniq_row = nullptr;
+  uint32_t* uniq_count = nullptr;
 };
 
 extern "C" {
@@ -1208,6 +1302,7 @@ int c4_session_destroy(c4_session* s) {
   (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts); (void)hipFree(s->p.cache);
   (void)hipFree(s->plan_dev); (void)hipFree(s->pairs_dev); (void)hipFree(s->offsets_dev); (void)hipFree(s->ln_tab_dev);
   if (s->total_host) (void)hipHostFree(s->total_host);
+  (void)hipFree(s->uniq_tab); (void)hipFree(s->uniq_cell); (void)hipFree(s->uniq_row); (void)hipFree(s->uniq_count);
   (void)hipFree(s->reqs_dev); (void)hipFree(s->start_mask_dev); (void)hipFree(s->start_value_dev);
   if (s->probe_host) (void)hipHostFree(s->probe_host);
   if (s->probe_event) (void)hipEventDestroy(s->probe_event);
@@ -1593,6 +1688,70 @@ int c4_session_leaf_keys(c4_session* s, int64_t* keys_dev) {
   if (!s || !keys_dev) return fail(C4_ERR_BAD_ARG, "null argument");
   C4_ON_DEVICE(s->cfg.device);
   hipLaunchKernelGGL(k_leaf_keys, dim3((s->cfg.n_slots + 255) / 256), dim3(256), 0, s->stream, s->p.slots, s->cfg.n_slots, (long long*)keys_dev);
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+// A pointer kernels of device `device` may use for `ptr`: device memory of that device as it is, pinned host
+// memory through its device mapping; anything else (pageable host memory, another device) is refused here,
+// where the message can say so, instead of faulting inside a kernel.
+static int device_view(const void* ptr, int device, const char* what, void** out) {
+  hipPointerAttribute_t attr{};
+  const hipError_t e = hipPointerGetAttributes(&attr, ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(C4_ERR_BAD_ARG, std::string(what) + " is neither device memory nor pinned host memory (" + hipGetErrorString(e) + ")");
+  }
+  if (attr.type == hipMemoryTypeHost) {
+    if (!attr.devicePointer) return fail(C4_ERR_BAD_ARG, std::string(what) + ": pinned host memory without a device mapping");
+    *out = attr.devicePointer;
+    return C4_OK;
+  }
+  if (attr.type == hipMemoryTypeManaged || (attr.type == hipMemoryTypeDevice && attr.device == device)) { *out = const_cast<void*>(ptr); return C4_OK; }
+  return fail(C4_ERR_BAD_ARG, std::string(what) + " is neither memory of device " + std::to_string(device) + " nor pinned host memory");
+}
+
+int c4_session_unique_leaves(c4_session* s, uint32_t* inverse_dev, float* rows_out, uint64_t* models_out, uint32_t* n_unique_out) {
+  if (!s || !inverse_dev || !rows_out || !n_unique_out) return fail(C4_ERR_BAD_ARG, "null argument");
+  if (!s->bound || !s->have_games) return fail(C4_ERR_BAD_ARG, "c4_session_unique_leaves: bind_io and set_games first");
+  C4_ON_DEVICE(s->cfg.device);
+  const uint32_t n = s->cfg.n_slots;
+  void *inv = nullptr, *rows = nullptr, *models = nullptr, *count = nullptr;
+  if (int rc = device_view(inverse_dev, s->cfg.device, "c4_session_unique_leaves: inverse_dev", &inv)) return rc;
+  if (int rc = device_view(rows_out, s->cfg.device, "c4_session_unique_leaves: rows_out", &rows)) return rc;
+  if (models_out) if (int rc = device_view(models_out, s->cfg.device, "c4_session_unique_leaves: models_out", &models)) return rc;
+  if (int rc = device_view(n_unique_out, s->cfg.device, "c4_session_unique_leaves: n_unique_out", &count)) return rc;
+  if (!s->uniq_tab) {
+    uint32_t cells = 64;
+    while (cells < 2 * n) cells <<= 1;                             // at most half full: short probe runs
+    HIP_TRY(hipMalloc(&s->uniq_tab, (size_t)cells * 4));
+    HIP_TRY(hipMemsetAsync(s->uniq_tab, 0xFF, (size_t)cells * 4, s->stream));   // empty; k_unique_emit keeps it so
+    HIP_TRY(hipMalloc(&s->uniq_cell, (size_t)n * 4));
+    HIP_TRY(hipMalloc(&s->uniq_row, (size_t)n * 4));
+    HIP_TRY(hipMalloc(&s->uniq_count, 4));
+    s->uniq_tab_mask = cells - 1;
+  }
+  hipLaunchKernelGGL(k_unique_insert, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->p.slots, s->p.leaf_models, n, s->uniq_tab,
+                     s->uniq_tab_mask, s->uniq_cell);
+  hipLaunchKernelGGL(k_unique_rank, dim3(1), dim3(1024), 0, s->stream, s->uniq_tab, s->uniq_cell, n, s->uniq_row, (uint32_t*)inv,
+                     s->uniq_count, (uint32_t*)count);
+  hipLaunchKernelGGL(k_unique_emit, dim3((n + 3) / 4), dim3(256), 0, s->stream, s->p.slots, s->p.leaf_models, n, s->uniq_tab,
+                     s->uniq_cell, s->uniq_row, (float*)rows, (uint64_t*)models);
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+int c4_session_scatter_outputs(c4_session* s, const uint32_t* inverse_dev, const float* answers, uint32_t n_unique) {
+  if (!s || !inverse_dev || (!answers && n_unique)) return fail(C4_ERR_BAD_ARG, "null argument");
+  if (!s->bound) return fail(C4_ERR_BAD_ARG, "c4_session_scatter_outputs: bind_io first");
+  if (n_unique == 0) return C4_OK;
+  C4_ON_DEVICE(s->cfg.device);
+  void *inv = nullptr, *ans = nullptr;
+  if (int rc = device_view(inverse_dev, s->cfg.device, "c4_session_scatter_outputs: inverse_dev", &inv)) return rc;
+  if (int rc = device_view(answers, s->cfg.device, "c4_session_scatter_outputs: answers", &ans)) return rc;
+  const uint32_t n = s->cfg.n_slots;
+  hipLaunchKernelGGL(k_unique_scatter, dim3((n * 9 + 255) / 256), dim3(256), 0, s->stream, (const uint32_t*)inv, (const float*)ans, n,
+                     n_unique, const_cast<float*>(s->p.logprobs), const_cast<float*>(s->p.q));
   HIP_TRY(hipGetLastError());
   return C4_OK;
 }

@@ -213,6 +213,25 @@ int c4_session_root_stats(c4_session* s, uint32_t slot, float policy[7], float* 
  * copying every slot to the host. */
 int c4_session_leaf_keys(c4_session* s, int64_t* keys_dev);
 
+/* The callback evaluator's batch, built on the device (NNThread::loop_once, self_play.rs:203-208: the
+ * reference collects the waiting leaves in a HashSet<(ModelID, Pos)> and evaluates each pair once).
+ * For the session's resident games, on its stream, without synchronising:
+ *   inverse_dev[n_slots]      row of each slot's (model, leaf position) pair in the batch, 0xFFFFFFFF for idle slots;
+ *   rows_out[n_unique][2][6][7] float32 evaluator input of each unique pair (c4r.rs:378-392, pybridge.rs:202-221);
+ *   models_out[n_unique]      its model id (mcts.rs:70-76; 0 without c4_session_bind_leaf_models), may be NULL;
+ *   *n_unique_out             the number of rows.
+ * Rows are ordered by the lowest slot holding the pair, so the batch depends on the games alone.
+ * inverse_dev is device memory; rows_out (capacity n_slots rows), models_out (n_slots) and n_unique_out may be
+ * device memory or PINNED HOST memory (hipHostMalloc / torch pin_memory): the kernels then write the
+ * batch across PCIe themselves and the host reads it after synchronising the stream.  Anything else
+ * (pageable host memory, another device's memory) is refused. */
+int c4_session_unique_leaves(c4_session* s, uint32_t* inverse_dev, float* rows_out, uint64_t* models_out, uint32_t* n_unique_out);
+/* The other half: answers[n_unique][9] (7 policy log-probabilities, q_penalty, q_no_penalty per row of the
+ * batch above; device or pinned host memory) to the bound logprobs / q rows of every slot that asked --
+ * what PyEvalPos hands back per position (pybridge.rs:161-199).  On the session's stream, no synchronisation:
+ * the caller keeps `answers` untouched until the stream has passed this point. */
+int c4_session_scatter_outputs(c4_session* s, const uint32_t* inverse_dev, const float* answers, uint32_t n_unique);
+
 /* Leaf position currently waiting for the evaluator, per slot (MctsGame::leaf_pos, mcts.rs:64-66);
  * status[g] = 1 active / 0 idle, ordinal[g] = index of the slot's game in reqs.  Host arrays of
  * n_slots (any may be NULL).  Synchronises.  Used by the numpy-callback compatibility mode. */

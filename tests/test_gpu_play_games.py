@@ -393,3 +393,82 @@ def test_leaf_keys_identify_positions():
     act = status == 1
     pos = {(int(m), int(v)) for m, v in zip(mask[act], value[act])}
     assert len(pos) == len(set(k[act].tolist()))
+
+
+def _unique_reference(mask, value, status, models):
+    """What c4_session_unique_leaves must produce, from the host's view of the slots: rows ordered by the
+    lowest slot holding each (model, position) pair."""
+    rows, inverse, seen = [], np.full(len(mask), 0xFFFFFFFF, dtype=np.uint32), {}
+    for g in range(len(mask)):
+        if status[g] != 1:
+            continue
+        pair = (int(models[g]) if models is not None else 0, int(mask[g]), int(value[g]))
+        if pair not in seen:
+            seen[pair] = len(rows)
+            rows.append(g)
+        inverse[g] = seen[pair]
+    return rows, inverse
+
+
+@pytest.mark.parametrize("pinned,multi", [(False, False), (True, False), (True, True)])
+def test_unique_leaves_and_scatter(pinned, multi):
+    """c4_session_unique_leaves + c4_session_scatter_outputs against a host restatement: one row per (model,
+    position) pair in lowest-slot order, the planes of c4r.rs:378-392, the slot -> row map, idle slots left out;
+    into device memory and into pinned host memory; the answers reach exactly the slots that asked.  Repeated
+    over the steps of a running session (the table must come back empty every time)."""
+    import ctypes as C
+    from c4a0_amd._lib import check
+    from c4a0_amd.session import DeviceSession
+    from tests.helpers import hash_eval_torch
+
+    n = 96
+    s = DeviceSession(n, 12, 6.6, 0.01)
+    s.set_games([(i, 7 if multi else 0, (1 << 63) + 5 if multi else 0) for i in range(70)])     # 26 idle slots
+    models_dev = s.bind_leaf_models() if multi else None
+    s.bind()
+    s.start()
+    dev = s.device
+    inverse = torch.zeros(n, dtype=torch.int32, device=dev)
+    mk = (lambda *shape, dtype: torch.zeros(*shape, dtype=dtype).pin_memory()) if pinned else (lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=dev))
+    rows_out, models_out, count = mk(n, 84, dtype=torch.float32), mk(n, dtype=torch.int64), mk(1, dtype=torch.int32)
+    answers = mk(n, 9, dtype=torch.float32)
+    for step in range(25):
+        s.evaluate(hash_eval_torch)
+        s.step()
+        if step % 4:
+            continue
+        check(s.L.c4_session_unique_leaves(s._h, C.c_void_p(inverse.data_ptr()), C.c_void_p(rows_out.data_ptr()),
+                                           C.c_void_p(models_out.data_ptr()) if multi else None, C.c_void_p(count.data_ptr())))
+        torch.cuda.synchronize()
+        mask, value, status = s.leaves()
+        models = models_dev.cpu().numpy() if multi else None
+        want_rows, want_inverse = _unique_reference(mask, value, status, models)
+        n_u = int(count.cpu()[0])
+        assert n_u == len(want_rows) and 0 < n_u < int((status == 1).sum())         # hash_eval games do collide early on
+        assert np.array_equal(inverse.cpu().numpy().view(np.uint32), want_inverse)
+        got = rows_out.cpu().numpy()[:n_u]
+        for r, g in enumerate(want_rows):
+            m, v = int(mask[g]), int(value[g])
+            mine = [(v >> i) & 1 for i in range(42)]
+            theirs = [((m ^ v) >> i) & 1 for i in range(42)]
+            assert got[r].tolist() == [float(b) for b in mine + theirs]
+        if multi:
+            assert np.array_equal(models_out.cpu().numpy()[:n_u], models[want_rows])
+        # answers: row r carries r + e / 16 in element e
+        a = (torch.arange(n_u, dtype=torch.float32)[:, None] + torch.arange(9, dtype=torch.float32)[None, :] / 16)
+        answers[:n_u] = a if pinned else a.to(dev)
+        before_lp, before_q = s.logprobs.clone(), s.q.clone()
+        check(s.L.c4_session_scatter_outputs(s._h, C.c_void_p(inverse.data_ptr()), C.c_void_p(answers.data_ptr()), n_u))
+        torch.cuda.synchronize()
+        lp, q = s.logprobs.cpu().numpy(), s.q.cpu().numpy()
+        for g in range(n):
+            if want_inverse[g] == 0xFFFFFFFF:
+                assert np.array_equal(lp[g], before_lp[g].cpu().numpy()) and np.array_equal(q[g], before_q[g].cpu().numpy())
+            else:
+                r = float(want_inverse[g])
+                assert lp[g].tolist() == [r + e / 16 for e in range(7)] and q[g].tolist() == [r + 7 / 16, r + 8 / 16]
+    # pageable host memory is refused, by name
+    bad = np.zeros((n, 84), dtype=np.float32)
+    rc = s.L.c4_session_unique_leaves(s._h, C.c_void_p(inverse.data_ptr()), C.c_void_p(bad.ctypes.data), None, C.c_void_p(count.data_ptr()))
+    assert rc != 0 and b"rows_out" in s.L.c4_last_error_string()
+    s.close()
