@@ -152,7 +152,12 @@ def whole_job(args, device, real_stdout):
 
     out, ref = {}, None
     for name, kw in (("device_mode", dict(evaluator=net)), ("device_callback_wrapper", dict(py_eval_pos_cb=c4a0_amd.DeviceCallback(net, device))),
-                     ("numpy_callback", dict(py_eval_pos_cb=cb))):
+                     ("numpy_callback", dict(py_eval_pos_cb=cb)),
+                     # EXTENSION rows (not the reference's algorithm, off by default): the evaluation cache answers a leaf
+                     # whose position the evaluator has already seen without an evaluator row -- same samples, because
+                     # the evaluator is a function of the position alone -- fewer lock-step rounds
+                     ("extension_eval_cache_device_mode", dict(evaluator=net, eval_cache_entries=1 << 24)),
+                     ("extension_eval_cache_numpy_callback", dict(py_eval_pos_cb=cb, eval_cache_entries=1 << 24))):
         st = {}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -162,6 +167,8 @@ def whole_job(args, device, real_stdout):
         ref = recs if ref is None else ref
         out[name] = {"games_per_s": n_games / dt, "sims_per_s": st["sims"] / dt, "seconds": dt, "steps": st["steps"],
                      "samples": int(len(recs)), "samples_identical_to_device_mode": bool(recs.tobytes() == ref.tobytes())}
+        if "eval_cache_entries" in kw:
+            out[name]["cache_hit_rate"] = st["eval_cache_hits"] / max(1, st["eval_cache_probes"])
     line = {"metric": "whole-job self-play games/sec, the reference's default job", "value": out["device_mode"]["games_per_s"], "unit": "games/s",
             "n_gpus": 1, "higher_is_better": True, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"src/c4a0/main.py:40-51 defaults: {n_games} games, n_mcts_iterations={n_iter}, max_nn_batch_size=2000, 1-block/32-ch ResNet (4 policy / 2 value layers) bf16"},
