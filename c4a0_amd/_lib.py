@@ -89,7 +89,7 @@ SIGNATURES = {
     "c4_expf_logf": (C.c_int, [_vp, C.c_uint64, C.c_int, _vp, _vp]),
     "c4_softmax7": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "c4_apply_temperature": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
-    "c4_conv_tower_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
+    "c4_conv_tower_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp]),
     "c4_linear_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "c4_head_out_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "c4_dirichlet": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_uint64, _vp, _vp]),

@@ -375,7 +375,7 @@ extern "C" {
 //   out_dev  bf16 [n_boards][42][C]   (cell-major, channels last)
 // Runs on the device `stream` belongs to (the current device for the null stream).
 int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w_dev, const float* bias_dev,
-                       uint32_t n_boards, uint32_t channels, uint32_t n_blocks, void* out_dev, void* stream) {
+                       uint32_t n_boards, uint32_t channels, uint32_t n_blocks, void* out_dev, uint32_t config, void* stream) {
   if (!planes_dev || !w0_dev || !bias_dev || !out_dev || (n_blocks && !w_dev)) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: null argument");
   if (channels != 32 && channels != 64) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: channels must be 32 or 64");
   if (n_boards == 0) return C4_OK;
@@ -383,17 +383,20 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   c4host::DeviceGuard guard(device);
   if (guard.error() != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: hipSetDevice: ") + hipGetErrorString(guard.error()));
   TowerParams p{(const uint16_t*)planes_dev, (const bf16x8*)w0_dev, (const bf16x8*)w_dev, bias_dev, (uint16_t*)out_dev, n_boards, n_blocks};
-  // experiment knob (tools/tower_ab.sh): 1 = 12 wavefronts per workgroup (27.3 vs 28.0 us alone at 2 048 boards, no
-  // difference in the bench), 7 = the 8-board variant at every size
-  static const int variant = [] { const char* e = getenv("C4_TOWER_VARIANT"); return e ? atoi(e) : 0; }();
-  if (channels == 32 && variant == 1) return launch_tower<32, 16, 768, 1>(p, n_boards, (hipStream_t)stream, device);
-  if (channels == 32 && variant == 7) return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
+  // config (what a workgroup owns, never a board's arithmetic): 0 = by size (below), 1 = 16 boards / 8 wavefronts,
+  // 2 = 8 boards / 8 wavefronts, 3 = 16 boards / 12 wavefronts (27.3 vs 28.0 us alone at 2 048 boards, no difference
+  // in the bench).  The 64-channel tower has one shape.
+  if (config > 3) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config must be 0 (automatic) .. 3");
+  if (channels == 32 && config == 1) return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);
+  if (channels == 32 && config == 2) return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
+  if (channels == 32 && config == 3) return launch_tower<32, 16, 768, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32 && n_boards <= 8 * 160)
     // small launches (up to 1 280 boards): 8 boards per workgroup, three tiles in flight per wave, so
     // that the launch spreads over twice as many CUs (2 048 boards alone: 31.6 -> 20.5 us).  NOT used for
     // the 2 048-board launches of two concurrent sessions: there the other session fills the rest of
     // the chip and what counts is CU-time per board, which is 30 % higher this way (measured: -1.7 %
-    // games/s at BASELINE config 2).
+    // games/s at BASELINE config 2); a caller whose launch has the chip to itself asks for config 2 up to
+    // 2 048 boards (c4a0_amd/nn.py latency_mode: 27.3 -> 19.1 us).
     return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32)
     return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);   // 8 waves: two per SIMD

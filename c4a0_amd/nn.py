@@ -125,7 +125,8 @@ class InferenceNet:
 
     latency_mode = False  # True while ONE session plays alone on the device (api._play sets it): the narrow layers of a
                           # > 1 024-row batch then use the 128 x 96 tile (12.7 vs 16.8 us alone at 1 700 rows; beside a
-                          # second session's kernels the fat 128 x 192 tile wins, c4_head_gemm.hip)
+                          # second session's kernels the fat 128 x 192 tile wins, c4_head_gemm.hip) and the 32-channel
+                          # tower 8 boards per workgroup up to 2 048 boards (27.3 -> 19.1 us alone at 2 048)
     graph_safe = True  # forward() is pure device work on caller-owned outputs: may be captured in a HIP graph
     stage_hook = None  # optional callable(stage): 0 = before the tower is launched, 1 = after the first hidden layer's
                        # GEMM is launched (session.capture_pair records / waits cross-stream events there)
@@ -199,6 +200,7 @@ class InferenceNet:
         # tile configuration: one number, or "wide,narrow" (the merged 2F-wide first layer, the F-wide layers); 0 = automatic
         cfg = str(gemm_config if gemm_config is not None else os.environ.get("C4A0_GEMM_CONFIG", "0")).split(",")
         self.gemm_config = (int(cfg[0]), int(cfg[-1]))
+        self.tower_config = int(os.environ.get("C4A0_TOWER_CONFIG", "0"))   # c4_conv_tower_bf16's config, 0 = automatic (tools/tower_ab.sh)
         mv = lambda ts: [t.to(self.device, dtype).contiguous() for t in ts]
         self.conv_w = [w.to(self.device, dtype).contiguous(memory_format=torch.channels_last) for w in self.conv_w]
         self.conv_b = mv(self.conv_b)
@@ -226,6 +228,8 @@ class InferenceNet:
             check(self._L.c4_conv_tower_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(self.tw0.data_ptr()),
                                              C.c_void_p(self.tw.data_ptr()), C.c_void_p(self.tbias.data_ptr()),
                                              g, self.channels, self.n_blocks, C.c_void_p(out.data_ptr()),
+                                             # alone on the device (latency_mode): 8 boards per workgroup up to 2 048 boards
+                                             self.tower_config or (2 if (self.latency_mode and self.channels == 32 and g <= 2048) else 0),
                                              C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             return out
         x = planes.to(self.dtype)

@@ -143,3 +143,30 @@ def test_head_output_kernel_vs_fp32_reference(features, n):
     # f32 accumulation of exact bf16 products on both sides: only the summation order differs
     assert (lp - want_lp).abs().max().item() < 2e-4, (lp - want_lp).abs().max().item()
     assert (q - want_q).abs().max().item() < 2e-4, (q - want_q).abs().max().item()
+
+
+def test_tower_workgroup_shapes_compute_the_same_bits():
+    """c4_conv_tower_bf16's config picks what a workgroup owns (16 or 8 boards, 8 or 12 wavefronts), never a
+    board's arithmetic: the same features bit for bit, at sizes on both sides of the automatic choice's cut,
+    with a ragged last workgroup; an unknown config is refused."""
+    import ctypes as C
+    from c4a0_amd._lib import lib
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    model = ConnectFourNet(ModelConfig(2, 32, 2, 2)).eval()
+    net = InferenceNet(model, dev, dtype=torch.bfloat16, hip_tower=True)
+    for n in (1, 37, 1280, 1283, 2048):
+        x = (torch.rand(n, 2, 6, 7) < 0.3).to(dev).bfloat16()
+        net.tower_config = 0
+        want = net.tower(x)
+        for cfg in (1, 2, 3):
+            net.tower_config = cfg
+            assert torch.equal(net.tower(x).view(torch.int16), want.view(torch.int16)), (n, cfg)
+    net.tower_config, net.latency_mode = 0, True       # alone on the device: the 8-board shape by itself
+    assert torch.equal(net.tower(x).view(torch.int16), want.view(torch.int16))
+    out = torch.empty((1, 42 * 32), dtype=torch.bfloat16, device=dev)
+    rc = lib().c4_conv_tower_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(net.tw0.data_ptr()), C.c_void_p(net.tw.data_ptr()), C.c_void_p(net.tbias.data_ptr()),
+                                  1, 32, 2, C.c_void_p(out.data_ptr()), 9, None)
+    assert rc != 0 and b"config" in lib().c4_last_error_string()

@@ -16,4 +16,6 @@ python tools/tree_roofline.py --games 2048,4096,16384,65536,131072 > $O/tree_swe
 bash tools/tower_ab.sh "2048 4096" > $O/tower.txt 2>&1
 python tools/tower_probe.py 64 8 2048 >> $O/tower.txt 2>&1
 python tools/callback_mode_rate.py 16384 > $O/callback_mode.txt 2>&1
+python tools/callback_breakdown.py 1700 1400 2>&1 | grep '^run' >> $O/callback_mode.txt
+python tools/callback_breakdown.py 8192 100 4 32 4 2 2>&1 | grep '^run' >> $O/callback_mode.txt
 ls -la $O
