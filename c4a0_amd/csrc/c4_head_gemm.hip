@@ -444,7 +444,14 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
   // Small batches (callback mode, tails, jobs of a few hundred games) want many small tiles: there a
   // layer is a latency chain, not CU-time (alone, us: M = 512 cfg 9 8.0 / 7.5 for the wide / narrow
   // layer against cfg 11's 16.4 / 15.5; M = 1024 cfg 10 12.3 wide, cfg 9 7.9 narrow).
-  if (config == 0) config = m <= 640 ? 9 : (m <= 1024 ? (n > k ? 10 : 9) : 11);
+  // Round 3, alone, us (tools/gemm_probe.py, wide / narrow): M = 256 cfg 27 6.6 / 6.2 (cfg 9 7.7 / 7.3); M = 512 cfg 9
+  // 8.2 wide, cfg 27 6.6 narrow; M = 768 cfg 23 10.0 wide (cfg 10 11.7), cfg 9 7.5 narrow.  Between 1 025 and 1 728
+  // rows a caller that has the chip to itself asks for cfg 23 (96 x 96, 72 KB: <= 2 x 256 workgroups, two per
+  // CU: 18.0 / 12.2 against 19.4 / 12.5 at 1 700 rows; c4a0_amd/nn.py latency_mode).
+  if (config == 0) {
+    const bool wide = n > k;
+    config = m <= 384 ? 27 : m <= 640 ? (wide ? 9 : 27) : m <= 896 ? (wide ? 23 : 9) : m <= 1024 ? (wide ? 10 : 9) : 11;
+  }
   switch (config) {
     case 1: return launch_gemm<128, 192, 2, 2, 2, 2>(p, st, device);   // 4 wavefronts (64 x 96 each), 80 KB: two workgroups per CU
     case 2: return launch_gemm<128, 192, 2, 4, 4, 1>(p, st, device);   // 8 wavefronts (64 x 48), 4-deep ring, the whole LDS
@@ -466,6 +473,14 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     case 18: return launch_gemm32<256, 192, 2, 4, 3>(p, st, device);   // ... 3-deep ring, 84 KB
     case 19: return launch_gemm32<256, 192, 4, 2, 4>(p, st, device);   // 8 wavefronts (64 x 96), 4-deep ring
     case 20: return launch_gemm<128, 192, 2, 4, 2, 2>(p, st, device);  // 8 wavefronts (64 x 48), 2-deep ring, 80 KB: two workgroups per CU
+    case 21: return launch_gemm<96, 192, 2, 2, 3, 1>(p, st, device);   // 4 wavefronts (48 x 96), 108 KB: 18 x 14 = 252 workgroups at 1 700 rows
+    case 22: return launch_gemm<96, 96, 2, 2, 4, 1>(p, st, device);    // 4 wavefronts (48 x 48), 4-deep ring, 96 KB: 252 workgroups for the F-wide layers
+    case 23: return launch_gemm<96, 96, 2, 2, 3, 1>(p, st, device);    // ... 3-deep ring, 72 KB
+    case 24: return launch_gemm<96, 192, 2, 2, 4, 1>(p, st, device);   // 4-deep ring, 144 KB
+    case 25: return launch_gemm<96, 96, 2, 3, 3, 1>(p, st, device);    // 6 wavefronts (48 x 32), 72 KB
+    case 26: return launch_gemm<192, 96, 2, 2, 2, 1>(p, st, device);   // 4 wavefronts (96 x 48), 2-deep ring, 72 KB
+    case 27: return launch_gemm<64, 64, 2, 2, 4, 2>(p, st, device);    // 4 wavefronts (32 x 32), 4-deep ring, 64 KB
+    case 28: return launch_gemm<96, 64, 2, 2, 3, 1>(p, st, device);    // 4 wavefronts (48 x 32), 60 KB
     default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
   }
 }

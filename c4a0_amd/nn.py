@@ -292,6 +292,17 @@ class InferenceNet:
         q = torch.tanh(v) if out_q is None else torch.tanh(v, out=out_q)
         return lp, q
 
+    def _alone_config(self, m: int, n: int, k: int) -> int:
+        """Tile configuration of a hidden layer when ONE session has the device to itself (latency_mode): above 1 024
+        rows the automatic choice is the fat tile that wins beside a second session's kernels; alone, up to 1 728 rows
+        the 96 x 96 tile (at most 2 x 256 workgroups, two per CU) and beyond that the 128 x 96 tile for the F-wide
+        layers are faster (c4_head_gemm.hip; every configuration computes the same bits).  0 = automatic."""
+        if not self.latency_mode or m <= 1024:
+            return 0
+        if m <= 1728:
+            return 23
+        return 0 if n > k else 10
+
     def _linear_relu(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         """ReLU(x W^T + b): the hand-written MFMA GEMM, or (gemm="hipblaslt") the library's with the bias
         and ReLU in its epilogue where available."""
@@ -304,7 +315,7 @@ class InferenceNet:
             y = torch.empty((m, n), dtype=torch.bfloat16, device=self.device)
             check(self._L.c4_linear_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(self._bias32[b.data_ptr()].data_ptr()),
                                          C.c_void_p(y.data_ptr()), m, n, k, x.stride(0), n, 1,
-                                         self.gemm_config[0 if n > k else 1] or (10 if (self.latency_mode and m > 1024 and n <= k) else 0),
+                                         self.gemm_config[0 if n > k else 1] or self._alone_config(m, n, k),
                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             return y
         if self.fused_epilogue:

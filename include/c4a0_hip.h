@@ -279,7 +279,7 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
  * a row depends on that row and the weights ONLY (one fixed summation order per element whatever m, the row
  * index or `config`): the evaluator is a function of the position, as the reference's is (one forward per
  * unique position, self_play.rs:203-237).  n % 192 == 0, k % 64 == 0 (42 * C features, C a multiple of 32);
- * config 0 = automatic, 1..20 = a specific tile configuration (tools/gemm_probe.py). */
+ * config 0 = automatic, 1..28 = a specific tile configuration (tools/gemm_probe.py). */
 int c4_linear_bf16(const void* x_dev, const void* w_dev, const float* bias_dev, void* y_dev, uint32_t m, uint32_t n,
                    uint32_t k, uint32_t ldx, uint32_t ldy, uint32_t relu, uint32_t config, void* stream);
 

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = list(range(1, 21))
+CONFIGS = list(range(1, 29))
 
 
 def _linear(L, x, w, b32, relu=1, config=0, out=None):

@@ -93,7 +93,8 @@ def main():
         b32 = b.float()
         y = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         row = {"hipblaslt": timeit(lambda: torch._addmm_activation(b, x, w.t(), use_gelu=False))}
-        for cfg in (range(1, 17) if "PROBE_ALL" in os.environ else (4, 9, 10, 11, 17, 18, 19)):
+        for cfg in ([int(c) for c in os.environ["PROBE_CFGS"].split(",")] if "PROBE_CFGS" in os.environ else
+                    range(1, 17) if "PROBE_ALL" in os.environ else (4, 9, 10, 11, 17, 18, 19)):
             row[f"hip{cfg}"] = timeit(lambda: hip_linear(x, w, b32, cfg, y))
         fl = 2 * M * F * N
         out["alone_us"][f"N{N}"] = {k: round(v, 2) for k, v in row.items()}
