@@ -12,10 +12,68 @@ from c4a0_amd.session import DeviceSession
 from oracle import c4oracle as O
 from tests.helpers import GraphSafeHashEval, hash_eval_torch, oracle_samples_by_game, samples_by_game
 
+import c4a0_amd
+from tests.helpers import hash_eval_np
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = random.Random(20260002)
-t0, n_jobs, n_games_total, n_errs = time.time(), 0, 0, 0
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20260002)
+t0, n_jobs, n_games_total, n_errs, n_cb_jobs = time.time(), 0, 0, 0, 0
+
+
+def player(model_id, x):      # every "model" prefers other columns (the oracle calls the same function)
+    lp, qp, qn = hash_eval_np(model_id, x)
+    return np.ascontiguousarray(np.roll(lp, int(model_id % 7), axis=1)), qp, qn
+
+
+def callback_job():
+    """play_games through the numpy callback (unique (model, position) batches built on the device,
+    c4_session_unique_leaves / c4_session_scatter_outputs), one or several models, against the oracle driven by the
+    same callback."""
+    global n_jobs, n_games_total, n_errs, n_cb_jobs
+    n_games = rng.choice([1, 2, 5, 9, 24, 70])
+    n_iter = rng.choice([2, 3, 5, 10, 25, 60])
+    cap = rng.choice([1, 3, 8, 64, 4096])
+    resident = rng.choice([None, 1, 3, 8, 33])
+    models = rng.choice([[0], [5], [0, 1], [3, 2**63 + 1, 2**64 - 1], [7, 8, 9, 10]])
+    c_expl, c_ply = rng.choice([0.5, 1.4, 6.6]), rng.choice([0.0, 0.01])
+    reqs = [(1000 + i, rng.choice(models), rng.choice(models)) for i in range(n_games)]
+    cfg = dict(callback=True, n_games=n_games, n_iter=n_iter, cap=cap, resident=resident, models=models, c_expl=c_expl, c_ply=c_ply)
+    batches = []
+
+    def cb(model_id, x):
+        assert x.dtype == np.float32 and x.shape[1:] == (2, 6, 7) and 0 < x.shape[0] <= cap and x.flags["C_CONTIGUOUS"], cfg
+        assert len({x[i].tobytes() for i in range(x.shape[0])}) == x.shape[0], cfg
+        batches.append(x)         # kept: nothing handed over may ever be overwritten
+        return player(model_id, x)
+
+    dev_err = ora_err = None
+    try:
+        got = c4a0_amd.play_games([c4a0_amd.GameMetadata(*r) for r in reqs], cap, n_iter, c_expl, c_ply, cb, resident_games=resident)
+    except C4Error as e:
+        dev_err = e
+    kept = [b.copy() for b in batches]
+    try:
+        want, _ = O.self_play(reqs, cap, n_iter, c_expl, c_ply, player)
+    except RuntimeError as e:
+        ora_err = e
+    assert (dev_err is None) == (ora_err is None), (cfg, dev_err, ora_err)
+    assert all(np.array_equal(a, b) for a, b in zip(batches, kept)), cfg
+    if dev_err is not None:
+        n_errs += 1
+        return
+    by_game = {r.metadata.game_id: [(x.mask, x.value, x.policy.tobytes(), x.q_penalty.tobytes(), x.q_no_penalty.tobytes()) for x in r.samples]
+               for r in got.results}
+    assert by_game == oracle_samples_by_game(want), cfg
+    assert [(r.metadata.game_id, r.metadata.player0_id, r.metadata.player1_id) for r in got.results] == reqs, cfg
+    n_jobs += 1
+    n_cb_jobs += 1
+    n_games_total += n_games
+
+
 while time.time() - t0 < budget:
+    if rng.random() < 0.3:
+        callback_job()
+        continue
     n_games = rng.choice([1, 2, 3, 7, 8, 9, 17, 40, 100])
     n_slots = rng.choice([1, 2, 7, 8, 9, 16, 33])
     n_iter = rng.choice([1, 2, 3, 5, 10, 25, 60, 150])
@@ -59,4 +117,5 @@ while time.time() - t0 < budget:
     assert got == oracle_samples_by_game(want), cfg
     n_jobs += 1
     n_games_total += len(ids)
-print(f"fuzz parity ok: {n_jobs} jobs, {n_games_total} games in {time.time() - t0:.0f} s; {n_errs} more jobs ended in the same panic on both sides")
+print(f"fuzz parity ok: {n_jobs} jobs ({n_cb_jobs} of them through the numpy callback, one or several models), {n_games_total} games in {time.time() - t0:.0f} s; "
+      f"{n_errs} more jobs ended in the same panic on both sides")
