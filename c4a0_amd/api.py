@@ -117,25 +117,30 @@ class _CallbackEvaluator:
 
 class _MultiModelEvaluator:
     """Device-mode tournaments (reference tournament.py:112-142): the step kernel publishes, per
-    slot, the model that must evaluate its leaf (mcts.rs:70-76); every model present in the batch
-    evaluates the batch and its rows are selected on the device.  Where the reference serves
-    one model per NN tick (self_play.rs:203-215), all leaves are answered every step; a game's
-    trajectory only depends on the answers to its own leaves."""
+    slot, the model that must evaluate its leaf (mcts.rs:70-76); the rows are grouped by model on
+    the device and every model present evaluates ITS rows only (a gathered batch), the answers are
+    scattered back to the slots.  Where the reference serves one model per NN tick
+    (self_play.rs:203-215), all leaves are answered every step; a game's trajectory only depends on
+    the answers to its own leaves.  Model ids are 64-bit patterns (ids >= 2^63 are negative in the
+    int64 tensor; they are matched to the evaluators' keys as unsigned)."""
 
     def __init__(self, session: DeviceSession, evaluators: dict):
-        self.s, self.evs = session, evaluators
+        self.s, self.evs = session, {int(k) & ((1 << 64) - 1): v for k, v in evaluators.items()}
         self.models = session.bind_leaf_models()
 
     def __call__(self, planes: torch.Tensor):
-        present = torch.unique(self.models).tolist()
         lp_out, q_out = self.s.logprobs, self.s.q
-        for mid in present:
-            if mid not in self.evs:
+        order = torch.argsort(self.models, stable=True)                # slots grouped by model, slot order within a model
+        ids, counts = torch.unique_consecutive(self.models[order], return_counts=True)
+        lo = 0
+        for mid, n in zip(ids.tolist(), counts.tolist()):             # one synchronisation per step
+            rows, lo = order[lo:lo + n], lo + n
+            ev = self.evs.get(mid & ((1 << 64) - 1))
+            if ev is None:
                 continue  # idle slots keep id 0 of an absent model
-            lp, q = self.evs[mid](planes)
-            sel = (self.models == mid)
-            lp_out.copy_(torch.where(sel[:, None], lp.reshape(-1, 7).float(), lp_out))
-            q_out.copy_(torch.where(sel[:, None], q.reshape(-1, 2).float(), q_out))
+            lp, q = ev(planes.index_select(0, rows))
+            lp_out.index_copy_(0, rows, lp.reshape(-1, 7).float())
+            q_out.index_copy_(0, rows, q.reshape(-1, 2).float())
         return lp_out, q_out
 
 

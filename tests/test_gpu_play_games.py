@@ -190,10 +190,29 @@ def test_device_mode_tournament_matches_callback_mode_and_oracle():
 
     pairings = list(itertools.permutations([3, 5, 9], 2)) * 2
     reqs = [c4a0_amd.GameMetadata(100 + i, p0, p1) for i, (p0, p1) in enumerate(pairings)]
-    got = c4a0_amd.play_games(reqs, 64, 8, 1.4, 0.01, evaluator={m: dev_player(m) for m in (3, 5, 9)}, resident_games=8)
+    seen = {3: 0, 5: 0, 9: 0}
+
+    def counting(mid):
+        f = dev_player(mid)
+
+        def g(planes):
+            seen[mid] += planes.shape[0]          # every model is handed its own rows only
+            return f(planes)
+        return g
+
+    stats = {}
+    got = c4a0_amd.play_games(reqs, 64, 8, 1.4, 0.01, evaluator={m: counting(m) for m in (3, 5, 9)}, resident_games=8, stats=stats)
     want, _ = O.self_play([(r.game_id, r.player0_id, r.player1_id) for r in reqs], 64, 8, 1.4, 0.01, np_player)
     assert _as_oracle_dict(got) == oracle_samples_by_game(want)
     assert all(0.0 <= r.player0_score() <= 1.0 for r in got.results)
+    assert 0 < sum(seen.values()) <= 8 * stats["steps"] and all(seen.values())
+    # 64-bit model ids: patterns >= 2^63 are routed like any other (they are negative in the device's int64 tensor)
+    big = (1 << 63) + 7
+    reqs_big = [c4a0_amd.GameMetadata(200 + i, *(pair if i % 2 else pair[::-1])) for i, pair in enumerate([(4, big)] * 6)]
+    got = c4a0_amd.play_games(reqs_big, 64, 8, 1.4, 0.01, evaluator={4: dev_player(4), big: dev_player(big % 7)}, resident_games=4)
+    want, _ = O.self_play([(r.game_id, r.player0_id, r.player1_id) for r in reqs_big], 64, 8, 1.4, 0.01,
+                          lambda m, x: np_player(m if m == 4 else big % 7, x))
+    assert _as_oracle_dict(got) == oracle_samples_by_game(want)
     with pytest.raises(KeyError):
         c4a0_amd.play_games(reqs, 64, 8, 1.4, 0.01, evaluator={3: dev_player(3)})
     with pytest.raises(TypeError):
