@@ -305,3 +305,19 @@ def test_to_records_round_trip():
     assert back == pgr
     r2, c2 = back.to_records()      # the lazy form hands the arrays straight back
     assert r2.tobytes() == recs.tobytes() and np.array_equal(c2, counts)
+
+
+def test_tile_choice_of_a_session_alone_on_the_device():
+    """InferenceNet._alone_config (host logic, no GPU): only a session that has the device to itself asks for the
+    small tiles, only between 1 025 and 1 728 rows for both layer widths, and the F-wide layers keep the 128 x 96 tile
+    beyond; otherwise the automatic choice (0) stands."""
+    from c4a0_amd.nn import InferenceNet
+
+    net = object.__new__(InferenceNet)
+    net.latency_mode = False
+    assert [net._alone_config(m, 2688, 1344) for m in (1, 1024, 1025, 1700, 4096)] == [0] * 5
+    net.latency_mode = True
+    assert net._alone_config(1024, 2688, 1344) == 0 and net._alone_config(1024, 1344, 1344) == 0
+    assert net._alone_config(1025, 2688, 1344) == 23 and net._alone_config(1728, 1344, 1344) == 23
+    assert net._alone_config(1729, 2688, 1344) == 0 and net._alone_config(1729, 1344, 1344) == 10
+    assert net._alone_config(4096, 2688, 2688) == 10          # the 64-channel net's F-wide layers (n == k)
