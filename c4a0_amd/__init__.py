@@ -11,7 +11,7 @@ from .results import GameMetadata, GameResult, PlayGamesResult, Sample  # noqa: 
 
 
 def __getattr__(name):  # torch / the HIP library are loaded on first use of the entry points
-    if name in ("play_games", "run_tui", "DeviceCallback"):
+    if name in ("play_games", "run_tui", "DeviceCallback", "trim_cached_memory"):
         from . import api
         return getattr(api, name)
     if name == "play_games_sharded":

@@ -80,6 +80,7 @@ SIGNATURES = {
     "c4_session_sample_store": (C.c_int, [_vp, _P(_vp), _P(_vp), _P(C.c_uint64)]),
     "c4_session_root_stats": (C.c_int, [_vp, C.c_uint32, _P(C.c_float), _P(C.c_float), _P(C.c_float),
                                         _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint64)]),
+    "c4_trim_cached_memory": (C.c_int, []),
     "c4_session_leaf_keys": (C.c_int, [_vp, _vp]),
     "c4_session_unique_leaves": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "c4_session_scatter_outputs": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),

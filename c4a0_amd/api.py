@@ -300,6 +300,14 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
     return recs, counts
 
 
+def trim_cached_memory() -> None:
+    """Give the tree arena that the library keeps for the next session (c4_trim_cached_memory, include/c4a0_hip.h)
+    back to the device: for callers that want every byte of HBM between two self-play phases."""
+    from ._lib import check, lib
+
+    check(lib().c4_trim_cached_memory())
+
+
 class DeviceCallback:
     """A `py_eval_pos_cb`-shaped object for unmodified callers (training.py:179-189 builds
     `lambda model_id, x: model.forward_numpy(x)`): calling it answers numpy batches exactly like the

@@ -29,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1176,6 +1177,7 @@ struct c4_session {
   unsigned long long* offsets_dev = nullptr;   // pack_samples: [n_games] record offsets + [1] total, sized by set_games
   unsigned long long* total_host = nullptr;    // pinned
   // c4_session_unique_leaves scratch (first use): table of slot indices, each slot's cell, its row, the count
+  size_t arena_bytes = 0;                      // of p.blocks (kept for the next session when this one is destroyed)
   uint32_t* uniq_tab = nullptr;
   uint32_t uniq_tab_mask = 0;
   uint32_t* uniq_cell = nullptr;
@@ -1204,6 +1206,48 @@ int c4_device_count(int* out) {
   if (out) *out = n;
   return C4_OK;
 }
+
+// The tree arena is by far a session's largest allocation (13 GB for the reference's default job: 1 700 slots x
+// (43 x 1 400 + 8) blocks) and the driver scrubs freed device memory before it hands it out again: a session created
+// right after one of that size was destroyed waited 0.6 s in hipMalloc (tools/whole_job_phases.py).  One freed arena
+// per process is therefore kept for the next session on the same device that fits it (no more than twice as big as
+// needed); nothing in it is ever read before it is written (blocks are bump-allocated per slot, c4_start_kernel
+// writes each slot's root).  c4_trim_cached_memory() gives it back; C4_ARENA_CACHE=0 switches the cache off.
+namespace {
+struct ArenaCache { void* ptr = nullptr; size_t bytes = 0; int device = -1; };
+ArenaCache g_arena_cache;
+std::mutex g_arena_mutex;
+bool arena_cache_enabled() {
+  static const bool on = [] { const char* e = getenv("C4_ARENA_CACHE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+hipError_t arena_acquire(int device, size_t bytes, void** out) {
+  {
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    ArenaCache& c = g_arena_cache;
+    if (c.ptr && c.device == device && c.bytes >= bytes && c.bytes / 2 <= bytes) {
+      *out = c.ptr;
+      c = ArenaCache{};
+      return hipSuccess;
+    }
+  }
+  return hipMalloc(out, bytes);
+}
+void arena_release(int device, void* ptr, size_t bytes) {
+  if (!ptr) return;
+  void* drop = ptr;
+  if (arena_cache_enabled()) {
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    ArenaCache& c = g_arena_cache;
+    if (!c.ptr || c.bytes < bytes) {       // keep the bigger one
+      drop = c.ptr;
+      if (drop && c.device != device) { c4host::DeviceGuard guard(c.device); (void)hipFree(drop); drop = nullptr; }
+      c = ArenaCache{ptr, bytes, device};
+    }
+  }
+  if (drop) (void)hipFree(drop);
+}
+}  // namespace
 
 static hipError_t reset_clock_acc(unsigned long long* acc_dev) {
   const unsigned long long init[5] = {0ull, 0ull, ~0ull, 0ull, 0ull};   // totals; running min start, max end, helpers done
@@ -1235,7 +1279,7 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   // one row of phase stamps per wavefront plus one per timing-helper workgroup (one helper per kWavesPerTimingHelper wavefronts)
   const size_t phase_rows = (size_t)s->n_waves_cap + (s->n_waves_cap + kWavesPerTimingHelper - 1) / kWavesPerTimingHelper + 1;
   if ((e = hipMalloc(&p.slots, n * sizeof(Slot))) != hipSuccess ||
-      (e = hipMalloc(&p.blocks, n * bps * sizeof(Block))) != hipSuccess ||
+      (e = arena_acquire(cfg->device, s->arena_bytes = n * bps * sizeof(Block), (void**)&p.blocks)) != hipSuccess ||
       (e = hipMalloc(&p.wave_ctr, (size_t)s->n_waves_cap * CTR_N * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.glob, sizeof(Globals))) != hipSuccess ||
       (e = hipMalloc(&p.stamps, (size_t)s->n_waves_cap * 4 * sizeof(unsigned long long))) != hipSuccess ||
@@ -1298,7 +1342,7 @@ int c4_session_destroy(c4_session* s) {
   if (!s) return C4_OK;
   c4host::DeviceGuard guard(s->cfg.device);
   if (s->stream) (void)hipStreamSynchronize(s->stream); else (void)hipDeviceSynchronize();
-  (void)hipFree(s->p.slots); (void)hipFree(s->p.blocks); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob); (void)hipFree(s->p.stamps); (void)hipFree(s->p.clock_acc); (void)hipFree(s->p.phase);
+  (void)hipFree(s->p.slots); arena_release(s->cfg.device, s->p.blocks, s->arena_bytes); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob); (void)hipFree(s->p.stamps); (void)hipFree(s->p.clock_acc); (void)hipFree(s->p.phase);
   (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts); (void)hipFree(s->p.cache);
   (void)hipFree(s->plan_dev); (void)hipFree(s->pairs_dev); (void)hipFree(s->offsets_dev); (void)hipFree(s->ln_tab_dev);
   if (s->total_host) (void)hipHostFree(s->total_host);
@@ -1307,6 +1351,20 @@ int c4_session_destroy(c4_session* s) {
   if (s->probe_host) (void)hipHostFree(s->probe_host);
   if (s->probe_event) (void)hipEventDestroy(s->probe_event);
   delete s;
+  return C4_OK;
+}
+
+int c4_trim_cached_memory(void) {
+  ArenaCache c;
+  {
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    c = g_arena_cache;
+    g_arena_cache = ArenaCache{};
+  }
+  if (c.ptr) {
+    c4host::DeviceGuard guard(c.device);
+    HIP_TRY(hipFree(c.ptr));
+  }
   return C4_OK;
 }
 

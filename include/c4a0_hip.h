@@ -112,6 +112,11 @@ int c4_device_count(int* out);
  * slot states and counters on `cfg->device`. */
 int c4_session_create(const c4_config* cfg, c4_session** out);
 int c4_session_destroy(c4_session* s);
+/* c4_session_destroy keeps ONE tree arena (a session's largest allocation: n_slots x blocks_per_slot x 128 bytes) per
+ * process for the next session on the same device that it fits -- the driver scrubs freed device memory before reuse,
+ * which a session created right after a big one was destroyed would otherwise wait for (0.6 s for 13 GB).  This gives
+ * the kept arena back to the device now.  C4_ARENA_CACHE=0 in the environment disables the cache. */
+int c4_trim_cached_memory(void);
 
 /* `reqs: Vec<GameMetadata>` of self_play() (self_play.rs:41).  Copies the list to the device,
  * allocates the sample store (43 records per game), resets queue and counters.

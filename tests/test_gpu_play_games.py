@@ -491,3 +491,27 @@ def test_unique_leaves_and_scatter(pinned, multi):
     rc = s.L.c4_session_unique_leaves(s._h, C.c_void_p(inverse.data_ptr()), C.c_void_p(bad.ctypes.data), None, C.c_void_p(count.data_ptr()))
     assert rc != 0 and b"rows_out" in s.L.c4_last_error_string()
     s.close()
+
+
+def test_arena_is_kept_for_the_next_session_and_can_be_trimmed():
+    """c4_session_destroy keeps one tree arena for the next session that fits it (the driver scrubs freed memory
+    before reuse: 0.6 s for the reference job's 13 GB); a reused arena holds the previous games' trees and nothing
+    of them may show: same samples as the oracle, three sessions in a row of sizes that do and do not fit;
+    trim_cached_memory() returns the memory (the device's free bytes go up by about the arena's size)."""
+    import c4a0_amd
+    from oracle import c4oracle as O
+    from tests.helpers import hash_eval_np, oracle_samples_by_game
+
+    c4a0_amd.trim_cached_memory()
+    free0, _ = torch.cuda.mem_get_info()
+    for n_games, resident, n_iter in ((40, 32, 60), (24, 24, 50), (70, 64, 9), (40, 32, 60)):
+        reqs = [c4a0_amd.GameMetadata(i, 0, 0) for i in range(n_games)]
+        got = c4a0_amd.play_games(reqs, 64, n_iter, 6.6, 0.01, hash_eval_np, resident_games=resident)
+        want, _ = O.self_play([(i, 0, 0) for i in range(n_games)], 64, n_iter, 6.6, 0.01, "hash")
+        assert _as_oracle_dict(got) == oracle_samples_by_game(want)
+    free1, _ = torch.cuda.mem_get_info()
+    c4a0_amd.trim_cached_memory()
+    free2, _ = torch.cuda.mem_get_info()
+    arena = 32 * (43 * 60 + 8) * 128                      # the biggest of the four
+    assert free2 - free1 >= arena // 2 and free0 - free1 >= arena // 2, (free0, free1, free2, arena)
+    c4a0_amd.trim_cached_memory()                          # nothing kept: still fine
