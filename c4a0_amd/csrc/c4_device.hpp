@@ -37,12 +37,14 @@ C4_DEV void make_move(uint64_t& mask, uint64_t& value, uint32_t col) {
 }
 
 // Four in a row among the bits of x (c4r.rs:165-224,241-249; any method, the result is boolean).
+// Per direction with stride s: bit i of the result = x[i] & x[i+s] & x[i+2s] & x[i+3s], folded pairwise (pairs first,
+// then pairs of pairs: two shifts per direction instead of three); the start-column mask keeps the horizontal and the
+// two diagonal lines inside their rows.
 C4_DEV bool has_four(uint64_t x) {
-  uint64_t h = x & (x >> 1) & (x >> 2) & (x >> 3) & kStart03;
-  uint64_t v = x & (x >> 7) & (x >> 14) & (x >> 21);
-  uint64_t d1 = x & (x >> 8) & (x >> 16) & (x >> 24) & kStart03;
-  uint64_t d2 = (x >> 3) & (x >> 9) & (x >> 15) & (x >> 21) & kStart03;
-  return (h | v | d1 | d2) != 0;
+  const uint64_t h2 = x & (x >> 1), v2 = x & (x >> 7), a2 = x & (x >> 8);
+  const uint64_t t = x >> 3, b2 = t & (t >> 6);                      // anti-diagonal: x[i+3], x[i+9], x[i+15], x[i+21]
+  const uint64_t h = h2 & (h2 >> 2), v = v2 & (v2 >> 14), d1 = a2 & (a2 >> 16), d2 = b2 & (b2 >> 12);
+  return (((h | d1 | d2) & kStart03) | v) != 0;
 }
 
 // c4r.rs:228-238: 0 none, 1 PlayerWin, 2 OpponentWin, 3 Draw -- in that order.
