@@ -18,4 +18,7 @@ python tools/tower_probe.py 64 8 2048 >> $O/tower.txt 2>&1
 python tools/callback_mode_rate.py 16384 > $O/callback_mode.txt 2>&1
 python tools/callback_breakdown.py 1700 1400 2>&1 | grep '^run' >> $O/callback_mode.txt
 python tools/callback_breakdown.py 8192 100 4 32 4 2 2>&1 | grep '^run' >> $O/callback_mode.txt
+bash tools/profile/whole_job_kernels.sh > $O/whole_job_kernels.txt 2>&1      # -> gpurun_out/wj/kernel_stats.csv
+bash tools/profile/callback_kernels.sh > $O/callback_kernels.txt 2>&1        # -> gpurun_out/cbk/kernel_stats.csv
+# counters under the evaluator (ten --pmc passes per backend, ~2 minutes): bash tools/profile/run_r03_eval_pmc.sh 2048 r03
 ls -la $O
