@@ -451,6 +451,10 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
   if (config == 0) {
     const bool wide = n > k;
     config = m <= 384 ? 27 : m <= 640 ? (wide ? 9 : 27) : m <= 896 ? (wide ? 23 : 9) : m <= 1024 ? (wide ? 10 : 9) : 11;
+    // The 64-channel net (K = 2 688, N = 5 376 / 2 688: four times the flops per layer): there the 256 x 192 tile
+    // (64 x 96 per wavefront, 2-deep ring, 112 KB) pays -- BASELINE config 4 (2 x 2 048 rows) 862 -> 925-939 games/s,
+    // config 5's per-GPU share (2 x 4 096 rows) 3 271 -> 3 671 (hipBLASLt: 911-919 / 3 736), profiles/r03_gemm_configs.txt
+    if (m > 1024 && k >= 2048) config = 7;
   }
   switch (config) {
     case 1: return launch_gemm<128, 192, 2, 2, 2, 2>(p, st, device);   // 4 wavefronts (64 x 96 each), 80 KB: two workgroups per CU

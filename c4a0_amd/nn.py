@@ -299,6 +299,8 @@ class InferenceNet:
         layers are faster (c4_head_gemm.hip; every configuration computes the same bits).  0 = automatic."""
         if not self.latency_mode or m <= 1024:
             return 0
+        if k >= 2048:   # the 64-channel net: the automatic 256 x 192 tile for the 2F-wide layer, 128 x 192 for the F-wide ones
+            return 0 if n > k else 11   # (alone at 2 048 rows: 31 us against 49)
         if m <= 1728:
             return 23
         return 0 if n > k else 10

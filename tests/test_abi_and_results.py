@@ -320,4 +320,6 @@ def test_tile_choice_of_a_session_alone_on_the_device():
     assert net._alone_config(1024, 2688, 1344) == 0 and net._alone_config(1024, 1344, 1344) == 0
     assert net._alone_config(1025, 2688, 1344) == 23 and net._alone_config(1728, 1344, 1344) == 23
     assert net._alone_config(1729, 2688, 1344) == 0 and net._alone_config(1729, 1344, 1344) == 10
-    assert net._alone_config(4096, 2688, 2688) == 10          # the 64-channel net's F-wide layers (n == k)
+    # the 64-channel net (k = 2 688): the automatic choice for the 2F-wide layer, the 128 x 192 tile for the F-wide ones
+    assert net._alone_config(4096, 2688, 2688) == 11 and net._alone_config(1500, 2688, 2688) == 11
+    assert net._alone_config(4096, 5376, 2688) == 0 and net._alone_config(1500, 5376, 2688) == 0

@@ -87,13 +87,15 @@ def test_bad_arguments_are_refused(ops):
         _linear(L, x[:8], w, b, config=77)
 
 
-def test_evaluator_is_batch_invariant():
+@pytest.mark.parametrize("blocks,channels", [(4, 32), (2, 64)])
+def test_evaluator_is_batch_invariant(blocks, channels):
     """The whole bf16 evaluator (tower + hand GEMMs + output kernel): a position's outputs do not depend
-    on the batch it is evaluated in (what makes play_games independent of mode and placement)."""
+    on the batch it is evaluated in (what makes play_games independent of mode and placement).  Both channel
+    counts: the automatic tile choice differs with K (256 x 192 above 1 024 rows at K = 2 688) and with the batch."""
     from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
     dev = torch.device("cuda:0")
     torch.manual_seed(1337)
-    net = InferenceNet(ConnectFourNet(ModelConfig(4, 32, 4, 2)), dev, dtype=torch.bfloat16)
+    net = InferenceNet(ConnectFourNet(ModelConfig(blocks, channels, 4, 2)), dev, dtype=torch.bfloat16)
     assert net.gemm == "hip"
     planes = (torch.rand(4096, 2, 6, 7, device=dev) < 0.3).to(torch.bfloat16)
     lp, q = net(planes)

@@ -83,7 +83,7 @@ def chain_pair(make_chain, n_rep=10, per_graph=10):
 
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    F = 1344
+    F = int(os.environ.get("PROBE_F", "1344"))   # 1344 = 42 x 32 channels, 2688 = 42 x 64
     out = {"M": M, "alone_us": {}, "pair_chain_us": {}}
     torch.manual_seed(0)
     for N in (2 * F, F):
