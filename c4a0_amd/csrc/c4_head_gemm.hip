@@ -454,7 +454,9 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     // The 64-channel net (K = 2 688, N = 5 376 / 2 688: four times the flops per layer): there the 256 x 192 tile
     // (64 x 96 per wavefront, 2-deep ring, 112 KB) pays -- BASELINE config 4 (2 x 2 048 rows) 862 -> 925-939 games/s,
     // config 5's per-GPU share (2 x 4 096 rows) 3 271 -> 3 671 (hipBLASLt: 911-919 / 3 736), profiles/r03_gemm_configs.txt
-    if (m > 1024 && k >= 2048) config = 7;
+    // Below that its layers want one size up from the 32-channel table (alone, us, wide / narrow: M = 256 cfg 9 13.8 /
+    // cfg 27 11.8; M = 512 cfg 10 21.4 / cfg 9 13.6; M = 1 024 cfg 11 30.9 / cfg 10 21.0).
+    if (k >= 2048) config = m <= 384 ? (wide ? 9 : 27) : m <= 640 ? (wide ? 10 : 9) : m <= 1024 ? (wide ? 11 : 10) : 7;
   }
   switch (config) {
     case 1: return launch_gemm<128, 192, 2, 2, 2, 2>(p, st, device);   // 4 wavefronts (64 x 96 each), 80 KB: two workgroups per CU
