@@ -220,6 +220,126 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
   after_last_tile();                                                  // after the last epilogue: fewer live registers
 }
 
+// The same layer with the loops the other way round, for C = 64 (round 3): k-steps OUTSIDE, the wavefront's cell tiles
+// inside.  Every accumulator still sums its k-steps in tap order (same bits as tower_layer), but a k-step's weight
+// fragments are needed once per layer, so they are STREAMED from global memory (L1/L2: all wavefront pairs of the
+// workgroup ask for the same lines) through a ring of kDepth k-steps instead of being held for the whole layer:
+// 48 registers instead of 144, and -- what this is about -- no wavefront ever waits for a layer's 36 KB after the
+// previous layer's last tile (counters, profiles/r03_tower64_pmc.json: half of the wave time was waiting, 4.4 us per
+// layer with the matrix pipe idle, 123 us per 2 048 boards of which 53 are MFMA time).  The ring runs across layer
+// boundaries (the layers' fragments are contiguous in global memory; kSteps % kDepth == 0 keeps the phase), so the
+// first k-steps of layer L + 1 are requested under the last MFMAs of layer L.  B fragments of k-step s + 1 (one per
+// tile) are read from LDS under the MFMAs of k-step s; the accumulators of all G_TILES tiles live in registers and the
+// epilogue (bias already in, ReLU / residual / convert / store) runs once per layer.
+template <int C, int NB, int G_TILES, int MTW, int kDepth, typename WQ>
+__device__ __forceinline__ void tower_layer_stream(const bool kSecond, const bool kLast, const uint4* __restrict__ src, uint4* __restrict__ dst, WQ& wq,
+                                                   const bf16x8* __restrict__ w_layer, bool has_next, const float* __restrict__ bias,
+                                                   int tile_lo, int m0, int lane, uint16_t* __restrict__ out = nullptr,
+                                                   uint32_t board0 = 0, uint32_t n_boards = 0) {
+  using G = Geo<C, NB>;
+  constexpr int kSteps = 9 * G::KC;
+  static_assert(kSteps % kDepth == 0, "the weight ring keeps its phase from layer to layer");
+  const int li = lane & 15, lg = lane >> 4;
+
+  // this layer's fragment of k-step s (tap s / KC, channel half s % KC), output-channel tile m0 + m; s >= kSteps
+  // continues into the next layer (same formula, kWFrags fragments further)
+  auto request = [&](int s) __attribute__((always_inline)) {
+    const int sl = s % kSteps;
+    const bf16x8* wl = w_layer + (s >= kSteps ? G::kWFrags * 64 : 0);
+#pragma unroll
+    for (int m = 0; m < MTW; m++) wq[s % kDepth][m] = wl[(((sl / G::KC) * G::MT + m0 + m) * G::KC + (sl % G::KC)) * 64 + lane];
+  };
+
+  int base[G_TILES], cell[G_TILES];
+  f32x4 acc[G_TILES][MTW];
+#pragma unroll
+  for (int g = 0; g < G_TILES; g++) {
+    const int tl = tile_lo + g;
+    const int bidx = tl / kTilesPerBoard;
+    cell[g] = 9 + 16 * (tl - bidx * kTilesPerBoard) + li;            // cell_slot of the tile's first cell is 9 + 16 j
+    base[g] = bidx * kBS + cell[g];
+#pragma unroll
+    for (int m = 0; m < MTW; m++) {
+      const float* bp = bias + 16 * (m0 + m) + 4 * lg;
+      acc[g][m] = f32x4{bp[0], bp[1], bp[2], bp[3]};
+    }
+  }
+  // B fragments.  The three taps of a board row are ONE fragment shifted by a lane: lane (lg, li) holds channels
+  // 8 lg .. 8 lg + 7 of padded cell c0 + li, the tap to the right needs cell c0 + li + 1 = lane li + 1's registers, the
+  // tap to the left lane li - 1's -- a DPP row shift (rows of 16 lanes = one lg), zero-filled at the row's ends, which
+  // is exactly right: cell c0 + 16 is the next tile's halo column (always zero) and lane 0 is itself a halo column whose
+  // output is never stored.  So LDS is read once per (tile, board row, channel half) instead of once per tap: a third
+  // of the fragment traffic -- the LDS port, loaded as heavily as the matrix pipe by the nine-reads-per-tile loop
+  // (8 wavefronts x 6 KB per k-step at 128 B per clock = 2 x 12 MFMAs x 16 cycles per SIMD), stops being a bound.
+  uint4 fr[2][G_TILES][G::KC];
+  auto read_row = [&](int r, int f) __attribute__((always_inline)) {           // board row r - 1 relative to the output cell, tap column 0
+    const int d = 8 * (r - 1);
+#pragma unroll
+    for (int g = 0; g < G_TILES; g++)
+#pragma unroll
+      for (int kc = 0; kc < G::KC; kc++) fr[f][g][kc] = src[(4 * kc + lg) * G::kPlane + base[g] + d];
+  };
+  auto shifted = [&](const uint4& v, int dc) __attribute__((always_inline)) {   // dc = 0: left neighbour's cell, 2: right neighbour's
+    if (dc == 1) return v;
+    uint4 o;
+    if (dc == 2) {          // row_shl:1 -- lane li reads lane li + 1
+      o.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x101, 0xF, 0xF, true); o.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x101, 0xF, 0xF, true);
+      o.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x101, 0xF, 0xF, true); o.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x101, 0xF, 0xF, true);
+    } else {                // row_shr:1 -- lane li reads lane li - 1
+      o.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x111, 0xF, 0xF, true); o.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x111, 0xF, 0xF, true);
+      o.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x111, 0xF, 0xF, true); o.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x111, 0xF, 0xF, true);
+    }
+    return o;
+  };
+  read_row(0, 0);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    // The fences pin the order the source states (hipcc's scheduler otherwise sinks every LDS read and every weight
+    // request to just in front of its first use and waits for it there: one round trip per pair of MFMAs).
+    if (r + 1 < 3) read_row(r + 1, (r + 1) & 1);                    // under this row's 6 KC k-steps
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dc = 0; dc < 3; dc++)
+#pragma unroll
+      for (int kc = 0; kc < G::KC; kc++) {
+        const int s = (3 * r + dc) * G::KC + kc;                    // k-steps in tap order, as tower_layer sums them
+#pragma unroll
+        for (int g = 0; g < G_TILES; g++) {
+          const uint4 bfrag = shifted(fr[r & 1][g][kc], dc);
+#pragma unroll
+          for (int m = 0; m < MTW; m++)
+            acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % kDepth][m], __builtin_bit_cast(bf16x8, bfrag), acc[g][m], 0, 0, 0);
+        }
+        if (s + kDepth < kSteps || has_next) request(s + kDepth);    // this ring slot is free again
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  }
+  // ---- epilogue: lane holds output channels 16 (m0 + m) + 4 lg + {0..3} of its cell of every tile
+#pragma unroll
+  for (int g = 0; g < G_TILES; g++) {
+    const bool valid = ((cell[g] - 1) & 7) != 0;                     // padded column 0 is halo: computed, never stored
+#pragma unroll
+    for (int m = 0; m < MTW; m++) {
+      uint2* op = reinterpret_cast<uint2*>(&dst[(2 * (m0 + m) + (lg >> 1)) * G::kPlane + base[g]]) + (lg & 1);
+      f32x4 v = acc[g][m];
+      if (kSecond) {
+        const uint2 o = *op;                                         // the residual stream: bf16 x4, widened by a shift
+        v[0] = __uint_as_float(o.x << 16) + fmaxf(v[0], 0.f); v[1] = __uint_as_float(o.x & 0xffff0000u) + fmaxf(v[1], 0.f);
+        v[2] = __uint_as_float(o.y << 16) + fmaxf(v[2], 0.f); v[3] = __uint_as_float(o.y & 0xffff0000u) + fmaxf(v[3], 0.f);
+      }
+      const bf16x4 o = __builtin_convertvector(v, bf16x4);
+      if (kLast) {
+        const int rc = cell[g] - 1, bcell = 7 * ((rc >> 3) - 1) + (rc & 7) - 1;
+        const uint32_t gb = board0 + (uint32_t)((tile_lo + g) / kTilesPerBoard);
+        if (valid && gb < n_boards)
+          *reinterpret_cast<uint2*>(out + ((size_t)gb * 42 + bcell) * C + 16 * (m0 + m) + 4 * lg) = __builtin_bit_cast(uint2, o);
+      } else if (valid) {
+        *op = __builtin_bit_cast(uint2, o);
+      }
+    }
+  }
+}
+
 // MS = 1: every wavefront computes all C/16 output-channel tiles of its cell tiles.  MS = 2 (C = 64):
 // the output-channel tiles are split over two wavefronts that share the cell tiles, which halves the
 // weights a wavefront holds (144 instead of 288 registers) so that two wavefronts fit on a SIMD.
@@ -234,11 +354,13 @@ __device__ __forceinline__ void dma_weights(const void* w, uint32_t bytes, uint4
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds_dst + c * 64), 16, lane * 16, (first_frag + c) * 1024, 0, 0);
 }
 
-template <int C, int NB, int NT, int MS>
+// ST (C = 64): the residual layers run as tower_layer_stream (weights streamed through a ring, k-steps outside).
+template <int C, int NB, int NT, int MS, bool ST = false>
 __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   using G = Geo<C, NB>;
   constexpr int MTW = G::MT / MS;
   static_assert(G::MT % MS == 0 && (!G::kStageW || MS == 1), "co-tile split");
+  static_assert(!ST || !G::kStageW, "streamed weights: the 64-channel tower");
   extern __shared__ __attribute__((aligned(256))) uint8_t lds_raw[];
   uint4* X = reinterpret_cast<uint4*>(lds_raw);    // block input / residual stream
   uint4* T = X + G::kBufSlots;                     // intermediate (and the conv0 input image)
@@ -311,6 +433,28 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   constexpr bool kFuseOut = (C == 32);             // C = 64 has no registers left for the global address arithmetic (it would spill)
   const int tile_lo = (wave / MS) * kTilesPerWave;
 
+  if constexpr (ST) {
+    constexpr int kDepth = 3;                        // k-steps of weights in flight: 3 x 12 MFMAs x 16 cycles ahead of their use
+    bf16x8 wq[kDepth][MTW];
+    if (n_layers >= 1) {                             // layer 1's first k-steps travel under conv0
+#pragma unroll
+      for (int sdx = 0; sdx < kDepth; sdx++)
+#pragma unroll
+        for (int m = 0; m < MTW; m++) wq[sdx][m] = p.w[(((sdx / G::KC) * G::MT + m0 + m) * G::KC + (sdx % G::KC)) * 64 + lane];
+    }
+    tower_layer<C, NB, true, false, false, kTilesPerWave, MTW, false>(T, X, wf, p.bias, tile_lo, m0, lane, [&]() __attribute__((always_inline)) {});
+    __syncthreads();
+    for (int layer = 1; layer <= n_layers; layer++) {
+      const bf16x8* wl = p.w + (size_t)(layer - 1) * G::kWFrags * 64;
+      const bool has_next = layer < n_layers;
+      const float* bl = p.bias + (size_t)layer * C;
+      const bool second = (layer & 1) == 0;          // second conv of a block: T -> X, += residual; the last one stores the tower's output
+      tower_layer_stream<C, NB, kTilesPerWave, MTW, kDepth>(second, layer == n_layers, second ? T : X, second ? X : T, wq, wl, has_next, bl, tile_lo, m0, lane,
+                                                            p.out, board0, p.n_boards);
+      if (layer == n_layers) return;
+      __syncthreads();                               // the wavefronts of a pair (and their neighbours' halo reads) meet between layers
+    }
+  } else {
   // conv0: input image (T) -> X
   tower_layer<C, NB, true, false, false, kTilesPerWave, MTW, kPrefetch>(T, X, wf, p.bias, tile_lo, m0, lane, [&]() __attribute__((always_inline)) {
     if (!G::kStageW && n_layers >= 1) load_layer_weights(1);
@@ -338,8 +482,9 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
     if (G::kStageW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  }
 
-  // ---- X -> out[g][cell][C] (C = 64, or no residual blocks: conv0's image is the output) ----
+  // ---- X -> out[g][cell][C] (C = 64 with held weights, or no residual blocks: conv0's image is the output) ----
   for (int i = tid; i < NB * 42 * G::KG; i += NT) {
     const int kg = i % G::KG;
     const int bc = i / G::KG;
@@ -352,10 +497,10 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   }
 }
 
-template <int C, int NB, int NT, int MS>
+template <int C, int NB, int NT, int MS, bool ST = false>
 int launch_tower(const TowerParams& p, uint32_t n_boards, hipStream_t stream, int device) {
   constexpr int kLds = Geo<C, NB>::kLdsBytes;
-  auto k = c4_conv_tower_kernel<C, NB, NT, MS>;
+  auto k = c4_conv_tower_kernel<C, NB, NT, MS, ST>;
   hipError_t e = c4host::opt_in_lds((const void*)k, kLds, device);
   if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: LDS opt-in (") + std::to_string(kLds) + " bytes) on device " + std::to_string(device) + ": " + hipGetErrorString(e));
   k<<<dim3((n_boards + NB - 1) / NB), dim3(NT), kLds, stream>>>(p);
@@ -400,7 +545,9 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
     return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32)
     return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);   // 8 waves: two per SIMD
-  return launch_tower<64, 8, 512, 2>(p, n_boards, (hipStream_t)stream, device);      // 8 wavefronts: pairs split the output channels, two per SIMD
+  static const int held = [] { const char* e = getenv("C4_TOWER64_HELD"); return e ? atoi(e) : 0; }();   // A/B: round 2's kernel (a layer's weights held in registers)
+  if (held) return launch_tower<64, 8, 512, 2>(p, n_boards, (hipStream_t)stream, device);
+  return launch_tower<64, 8, 512, 2, true>(p, n_boards, (hipStream_t)stream, device);   // 8 wavefronts: pairs split the output channels; weights streamed
 }
 
 }  // extern "C"
