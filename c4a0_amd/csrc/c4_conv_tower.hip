@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   using G = Geo<C, NB>;
   constexpr int MTW = G::MT / MS;
   static_assert(G::MT % MS == 0 && (!G::kStageW || MS == 1), "co-tile split");
-  static_assert(!ST || !G::kStageW, "streamed weights: the 64-channel tower");
+
   extern __shared__ __attribute__((aligned(256))) uint8_t lds_raw[];
   uint4* X = reinterpret_cast<uint4*>(lds_raw);    // block input / residual stream
   uint4* T = X + G::kBufSlots;                     // intermediate (and the conv0 input image)
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
       for (int m = 0; m < MTW; m++)
         wf[k][m] = __builtin_bit_cast(bf16x8, ws[(((k / G::KC) * G::MT + m0 + m) * G::KC + (k % G::KC)) * 64 + lane]);
   };
-  if (G::kStageW) stage_layer_weights(1);
+  if (G::kStageW && !ST) stage_layer_weights(1);
 
   // ---- the input planes are requested first (a global round trip), then both images are zeroed under
   // that latency (halo cells stay zero for the whole kernel), then the planes go in: channel group 0 of T
@@ -474,7 +474,11 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
         for (int m = 0; m < MTW; m++) wq[sdx][m] = p.w[(((sdx / G::KC) * G::MT + m0 + m) * G::KC + (sdx % G::KC)) * 64 + lane];
     }
     tower_layer<C, NB, true, false, false, kTilesPerWave, MTW, false>(T, X, wf, p.bias, tile_lo, m0, lane, [&]() __attribute__((always_inline)) {});
-    __syncthreads();
+    // MS == 1 with whole boards per wavefront: a wavefront's layer L + 1 reads only what its own layer L wrote (and
+    // zero rows), LDS operations of one wavefront execute in order -- no barrier between layers, the two wavefronts of
+    // a SIMD drift apart and one's epilogue runs under the other's MFMAs
+    constexpr bool kBarrier = !(MS == 1 && kTilesPerWave % kTilesPerBoard == 0);
+    if (kBarrier) __syncthreads();
     for (int layer = 1; layer <= n_layers; layer++) {
       const bf16x8* wl = p.w + (size_t)(layer - 1) * G::kWFrags * 64;
       const bool has_next = layer < n_layers;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
       tower_layer_stream<C, NB, kTilesPerWave, MTW, kDepth>(second, layer == n_layers, second ? T : X, second ? X : T, wq, wl, has_next, bl, tile_lo, m0, lane,
                                                             p.out, board0, p.n_boards);
       if (layer == n_layers) return;
-      __syncthreads();                               // the wavefronts of a pair (and their neighbours' halo reads) meet between layers
+      if (kBarrier) __syncthreads();                 // the wavefronts of a pair (and their neighbours' halo reads) meet between layers
     }
   } else {
   // conv0: input image (T) -> X
@@ -515,6 +519,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
   }
   }
 
+  if (ST) __syncthreads();   // (streamed path without residual blocks: every thread copies conv0's image out)
   // ---- X -> out[g][cell][C] (C = 64 with held weights, or no residual blocks: conv0's image is the output) ----
   for (int i = tid; i < NB * 42 * G::KG; i += NT) {
     const int kg = i % G::KG;
@@ -574,6 +579,8 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
     // games/s at BASELINE config 2); a caller whose launch has the chip to itself asks for config 2 up to
     // 2 048 boards (c4a0_amd/nn.py latency_mode: 27.3 -> 19.1 us).
     return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
+  static const int st32 = [] { const char* e = getenv("C4_TOWER32_STREAM"); return e ? atoi(e) : 0; }();   // experiment
+  if (channels == 32 && st32) return launch_tower<32, 16, 512, 1, true>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32)
     return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);   // 8 waves: two per SIMD
   static const int held = [] { const char* e = getenv("C4_TOWER64_HELD"); return e ? atoi(e) : 0; }();   // A/B: round 2's kernel (a layer's weights held in registers)
