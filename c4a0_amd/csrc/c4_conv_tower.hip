@@ -447,6 +447,8 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
     if (i < NB * 42 && g < p.n_boards) in_v[j] = (uint32_t)p.planes[(size_t)g * 84 + cell] | ((uint32_t)p.planes[(size_t)g * 84 + 42 + cell] << 16);
   }
   for (int i = tid; i < 2 * G::kBufSlots; i += NT) X[i] = make_uint4(0, 0, 0, 0);
+  int* pair_ctr = reinterpret_cast<int*>(lds_raw + G::kLdsBytes);   // ST only: one counter per MS-group of wavefronts
+  if (ST && tid < 16) pair_ctr[tid] = 0;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < kIn; j++) {
@@ -487,7 +489,18 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
       tower_layer_stream<C, NB, kTilesPerWave, MTW, kDepth>(second, layer == n_layers, second ? T : X, second ? X : T, wq, wl, has_next, bl, tile_lo, m0, lane,
                                                             p.out, board0, p.n_boards);
       if (layer == n_layers) return;
-      if (kBarrier) __syncthreads();                 // the wavefronts of a pair (and their neighbours' halo reads) meet between layers
+      if (kBarrier) {
+        // Only the MS wavefronts that share cell tiles must meet between layers (each wrote its share of the output
+        // channels of the group's boards; a group's taps reach nothing else that is ever stored).  A workgroup barrier
+        // would also line up the two wavefronts of every SIMD -- they belong to different groups -- so that both run
+        // their once-per-layer epilogue at the same time with the matrix pipe idle.  Instead each group counts arrivals
+        // in LDS: LDS operations of a wavefront execute in order, so whoever sees the count sees the stores before it.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        int* ctr = pair_ctr + wave / MS;
+        if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < MS * layer) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
     }
   } else {
   // conv0: input image (T) -> X
@@ -535,7 +548,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
 
 template <int C, int NB, int NT, int MS, bool ST = false>
 int launch_tower(const TowerParams& p, uint32_t n_boards, hipStream_t stream, int device) {
-  constexpr int kLds = Geo<C, NB>::kLdsBytes;
+  constexpr int kLds = Geo<C, NB>::kLdsBytes + (ST ? 64 : 0);   // + the wavefront pairs' hand-over counters
   auto k = c4_conv_tower_kernel<C, NB, NT, MS, ST>;
   hipError_t e = c4host::opt_in_lds((const void*)k, kLds, device);
   if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: LDS opt-in (") + std::to_string(kLds) + " bytes) on device " + std::to_string(device) + ": " + hipGetErrorString(e));
