@@ -273,6 +273,10 @@ def main():
     ap.add_argument("--independent-graphs", action="store_true",
                     help="A/B knob: two sessions replay two independent graphs (round 1-2) instead of ONE graph that pipelines them "
                          "explicitly (session.capture_pair)")
+    ap.add_argument("--gemm", default=None, choices=["hip", "hipblaslt"],
+                    help="A/B knob: hidden-layer GEMM backend (default: the hand-written batch-invariant MFMA GEMM)")
+    ap.add_argument("--gemm-config", default=None, help="A/B knob: c4_linear_bf16 tile configuration, N or 'wide,narrow' (0 = automatic)")
+    ap.add_argument("--tower-config", type=int, default=0, help="A/B knob: c4_conv_tower_bf16 workgroup shape (0 = automatic)")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="internal: compute the cpu_baseline object alone and print it (the bench runs this leg in a child "
                          "process under a time limit, so that the checker can never cost the GPU line)")
@@ -312,7 +316,8 @@ def main():
     G, n_iter = args.games_per_gpu, args.n_mcts
     cfg = ModelConfig(args.blocks, args.channels, 4, 2)
     torch.manual_seed(1337)
-    net = InferenceNet(ConnectFourNet(cfg), device, dtype=torch.bfloat16)
+    net = InferenceNet(ConnectFourNet(cfg), device, dtype=torch.bfloat16, gemm=args.gemm, gemm_config=args.gemm_config,
+                       tower_config=args.tower_config)
 
     P = 1 if args.eager else max(1, min(args.sessions, G))
     R = max(1, args.rounds_per_step)

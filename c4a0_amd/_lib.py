@@ -19,6 +19,7 @@ STATUS_NAMES = {
 FLAG_NO_MOVES = 1
 FLAG_ONE_SIM_PER_STEP = 2
 MAX_SAMPLES_PER_GAME = 43
+ABI_VERSION = 4   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
 
 
 class C4Error(RuntimeError):
@@ -57,6 +58,7 @@ _P = C.POINTER
 _vp = C.c_void_p
 SIGNATURES = {
     "c4_last_error_string": (C.c_char_p, []),
+    "c4_abi_version": (C.c_int, []),
     "c4_source_hash": (C.c_char_p, []),
     "c4_device_count": (C.c_int, [_P(C.c_int)]),
     "c4_session_create": (C.c_int, [_P(Config), _P(_vp)]),
@@ -119,6 +121,8 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if L.c4_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} implements C ABI version {L.c4_abi_version()}, this binding is written for {ABI_VERSION}")
         # a library compiled from other sources than the ones beside it is refused, not used
         # (C4A0_HIP_LIB names a diagnostic build with its own flags: not compared)
         if "C4A0_HIP_LIB" not in os.environ:

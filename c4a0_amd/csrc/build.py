@@ -55,12 +55,14 @@ def is_stale(path: str = OUT, extra_flags=()) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
-    """diag=True builds libc4a0_hip_diag.so with in-kernel phase stamps (tools/phase_profile.py).
+    """diag=True builds libc4a0_hip_diag.so with in-kernel phase stamps (tools/phase_profile.py) and the measured
+    alternative kernels behind their environment knobs (C4_DIAG_VARIANTS: C4_TOWER32_STREAM, C4_TOWER64_HELD,
+    C4_STEP_LDS_BYTES); the product library reads no tuning knob from the environment.
     The library is compiled beside its final place and renamed over it, so a failed compile never
     destroys a working one."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = OUT.replace(".so", "_diag.so") if diag else OUT
-    extra = ["-DC4_PHASE_STAMPS"] if diag else []
+    extra = ["-DC4_PHASE_STAMPS", "-DC4_DIAG_VARIANTS"] if diag else []
     if force or is_stale(out, extra):
         tmp = out + ".tmp%d" % os.getpid()
         cmd = [hipcc] + FLAGS + extra + ['-DC4_SOURCE_HASH="%s"' % source_hash(extra)] + SRCS + ["-o", tmp]

@@ -34,14 +34,6 @@
 #include "../../include/c4a0_hip.h"
 #include "c4_host.hpp"
 
-// tower_layer (the tile-major loop of the 32-channel tower) can take the side taps of a board row from the centre tap's
-// fragment by DPP row shifts, as tower_layer_stream always does: a third of the LDS fragment reads, 26 registers
-// fewer, 24 more vector instructions per tile.  Measured neutral there (27.7 vs 28.2 us per 2 048 boards, same games/s:
-// its three pipes are loaded equally, profiles/r03_tower.txt), so the default stays the nine reads.
-#ifndef C4_TOWER_DPP_TAPS
-#define C4_TOWER_DPP_TAPS 0
-#endif
-
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -115,7 +107,6 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
   using G = Geo<C, NB>;
   constexpr int kSteps = kConv0 ? 3 : 9 * G::KC;        // MFMA k-steps (= B fragments) per tile
   constexpr int NF = kPrefetch ? 2 : 1;                 // fragment sets
-  constexpr bool kDppTaps = !kConv0 && C4_TOWER_DPP_TAPS;   // experiment: one LDS read per board row, the side taps by DPP row shifts
   const int li = lane & 15, lg = lane >> 4;
 
   f32x4 bias4[MTW];   // this wavefront's output-channel tiles are m0 .. m0 + MTW - 1
@@ -153,27 +144,11 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
         plane = 0;
       } else {
         const int t = k / G::KC, kc = k % G::KC;
-        if (kDppTaps && (t % 3) != 1) continue;          // the row's left and right taps are lane shifts of its centre tap (mfmas)
         d = 8 * (t / 3 - 1) + (t % 3 - 1);
         plane = 4 * kc + lg;
       }
       fr[f][k] = src[plane * G::kPlane + base + d];
     }
-  };
-  // tap column dc (0 left, 1 centre, 2 right) of a row from the centre tap's fragment: lane (lg, li) holds 8 channels of
-  // padded cell c0 + li, the neighbouring cell's are in lane li -+ 1 of the same 16-lane row; zero fill at the row's ends
-  // is right (cell c0 + 16 is the next tile's always-zero halo column, lane 0 is itself a halo column, never stored)
-  auto shifted = [&](const uint4& v, int dc) __attribute__((always_inline)) {
-    if (dc == 1) return v;
-    uint4 o;
-    if (dc == 2) {
-      o.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x101, 0xF, 0xF, true); o.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x101, 0xF, 0xF, true);
-      o.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x101, 0xF, 0xF, true); o.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x101, 0xF, 0xF, true);
-    } else {
-      o.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x111, 0xF, 0xF, true); o.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x111, 0xF, 0xF, true);
-      o.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x111, 0xF, 0xF, true); o.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x111, 0xF, 0xF, true);
-    }
-    return o;
   };
   // 8-byte half of the 16-byte slot of channel group 2 (m0 + m) + lg / 2 for this lane's cell
   auto out_ptr = [&](int slot_in_plane, int m) __attribute__((always_inline)) {
@@ -191,14 +166,9 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
   auto mfmas = [&](int f, int a) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < kSteps; k++) {
-      uint4 b = fr[f][k];
-      if (kDppTaps) {
-        const int t = k / G::KC, kc = k % G::KC;
-        b = shifted(fr[f][(3 * (t / 3) + 1) * G::KC + kc], t % 3);
-      }
 #pragma unroll
       for (int m = 0; m < MTW; m++)
-        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k][m], __builtin_bit_cast(bf16x8, b), acc[a][m], 0, 0, 0);
+        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k][m], __builtin_bit_cast(bf16x8, fr[f][k]), acc[a][m], 0, 0, 0);
     }
   };
   // lane holds output channels 16 m + 4 lg + {0..3} of its cell
@@ -592,12 +562,14 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
     // games/s at BASELINE config 2); a caller whose launch has the chip to itself asks for config 2 up to
     // 2 048 boards (c4a0_amd/nn.py latency_mode: 27.3 -> 19.1 us).
     return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
-  static const int st32 = [] { const char* e = getenv("C4_TOWER32_STREAM"); return e ? atoi(e) : 0; }();   // experiment
+#ifdef C4_DIAG_VARIANTS   // diagnostic build only (build.py --diag): measured alternatives, not part of libc4a0_hip.so
+  static const int st32 = [] { const char* e = getenv("C4_TOWER32_STREAM"); return e ? atoi(e) : 0; }();   // the streamed layer at 32 channels (slower there)
   if (channels == 32 && st32) return launch_tower<32, 16, 512, 1, true>(p, n_boards, (hipStream_t)stream, device);
+  static const int held = [] { const char* e = getenv("C4_TOWER64_HELD"); return e ? atoi(e) : 0; }();   // round 2's 64-channel kernel (a layer's weights held in registers)
+  if (channels == 64 && held) return launch_tower<64, 8, 512, 2>(p, n_boards, (hipStream_t)stream, device);
+#endif
   if (channels == 32)
     return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);   // 8 waves: two per SIMD
-  static const int held = [] { const char* e = getenv("C4_TOWER64_HELD"); return e ? atoi(e) : 0; }();   // A/B: round 2's kernel (a layer's weights held in registers)
-  if (held) return launch_tower<64, 8, 512, 2>(p, n_boards, (hipStream_t)stream, device);
   return launch_tower<64, 8, 512, 2, true>(p, n_boards, (hipStream_t)stream, device);   // 8 wavefronts: pairs split the output channels; weights streamed
 }
 

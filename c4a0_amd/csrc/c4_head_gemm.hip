@@ -108,7 +108,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmPa
   // buffer_load ... lds (MUBUF): descriptor + 32-bit per-lane offset + the k-tile's scalar offset.  (The
   // flat-encoded global_load_lds makes hipcc treat every later LDS wait as lgkmcnt(0); the MUBUF form
   // counts on vmcnt only, so the fragment reads below get counted lgkmcnt waits.)
-  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.M * p.ldx * 2u), 0x00020000);
+  // num_records ends with the last row's K elements, not with its stride: X may be a column view of a wider tensor
+  // (ldx > K), and the pieces issued past the last k-tile must then be clamped to zero by the bounds check instead of
+  // reading beyond the allocation
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((p.M - 1) * p.ldx + p.K) * 2u), 0x00020000);
   const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(p.N * p.K * 2u), 0x00020000);
   auto issue_one = [&](int kt, int i) __attribute__((always_inline)) {
     uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void c4_head_gemm32_kernel(GemmPar
       src_off[i] = (uint32_t)(tn0 + row) * p.K * 2u + (uint32_t)((slot ^ swz(row)) * 16);
     }
   }
-  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.M * p.ldx * 2u), 0x00020000);
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((p.M - 1) * p.ldx + p.K) * 2u), 0x00020000);   // see above
   const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(p.N * p.K * 2u), 0x00020000);
   auto issue_one = [&](int kt, int i) __attribute__((always_inline)) {
     if (i == L - 1 && short_wave) return;

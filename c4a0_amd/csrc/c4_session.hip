@@ -1188,6 +1188,7 @@ struct c4_session {
 extern "C" {
 
 const char* c4_last_error_string(void) { return g_last_error.c_str(); }
+int c4_abi_version(void) { return C4_ABI_VERSION; }
 
 #ifndef C4_SOURCE_HASH
 #define C4_SOURCE_HASH "unknown"
@@ -1221,6 +1222,19 @@ bool arena_cache_enabled() {
   static const bool on = [] { const char* e = getenv("C4_ARENA_CACHE"); return !(e && e[0] == '0'); }();
   return on;
 }
+// Gives the kept arena back to its device (the caller holds no lock).  Returns true if there was one.
+bool arena_drop_cached() {
+  ArenaCache old;
+  {
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    old = g_arena_cache;
+    g_arena_cache = ArenaCache{};
+  }
+  if (!old.ptr) return false;
+  c4host::DeviceGuard guard(old.device);
+  (void)hipFree(old.ptr);
+  return true;
+}
 hipError_t arena_acquire(int device, size_t bytes, void** out) {
   {
     std::lock_guard<std::mutex> lock(g_arena_mutex);
@@ -1231,7 +1245,12 @@ hipError_t arena_acquire(int device, size_t bytes, void** out) {
       return hipSuccess;
     }
   }
-  return hipMalloc(out, bytes);
+  hipError_t e = hipMalloc(out, bytes);
+  if (e == hipErrorOutOfMemory && arena_drop_cached()) {   // a kept arena that does not fit this request must not cause its failure
+    (void)hipGetLastError();
+    e = hipMalloc(out, bytes);
+  }
+  return e;
 }
 void arena_release(int device, void* ptr, size_t bytes) {
   if (!ptr) return;
@@ -1505,9 +1524,13 @@ int c4_session_step(c4_session* s) {
   // the Dirichlet-noise and evaluation-cache extensions are separate instantiations: the default
   // kernel carries none of their registers or scratch
   const bool noise = s->p.dir_eps > 0.0f, cache = s->p.cache != nullptr;
-  // C4_STEP_LDS_BYTES (diagnostic, tools/occupancy_probe.sh): unused dynamic LDS per workgroup caps the
+#ifdef C4_DIAG_VARIANTS
+  // C4_STEP_LDS_BYTES (diagnostic build only, tools/occupancy_probe.sh): unused dynamic LDS per workgroup caps the
   // wavefronts a CU holds (160 KB / bytes) without touching the code: how the launch time scales with occupancy
   static const unsigned lds_pad = [] { const char* e = getenv("C4_STEP_LDS_BYTES"); return e ? (unsigned)atoi(e) : 0u; }();
+#else
+  constexpr unsigned lds_pad = 0;
+#endif
   // a timed launch (seq != 0) carries extra workgroups that fold the previous launch's stamps
   const uint32_t helpers = s->p.seq ? (s->n_waves + kWavesPerTimingHelper - 1) / kWavesPerTimingHelper : 0u;
   auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(s->n_waves + helpers), dim3(64), lds_pad, s->stream, s->p); };
@@ -1782,11 +1805,19 @@ int c4_session_unique_leaves(c4_session* s, uint32_t* inverse_dev, float* rows_o
   if (!s->uniq_tab) {
     uint32_t cells = 64;
     while (cells < 2 * n) cells <<= 1;                             // at most half full: short probe runs
-    HIP_TRY(hipMalloc(&s->uniq_tab, (size_t)cells * 4));
-    HIP_TRY(hipMemsetAsync(s->uniq_tab, 0xFF, (size_t)cells * 4, s->stream));   // empty; k_unique_emit keeps it so
-    HIP_TRY(hipMalloc(&s->uniq_cell, (size_t)n * 4));
-    HIP_TRY(hipMalloc(&s->uniq_row, (size_t)n * 4));
-    HIP_TRY(hipMalloc(&s->uniq_count, 4));
+    // all four or none: the session's fields are set only when every allocation succeeded (a half-made table with
+    // mask 0 would send the next call's kernels through null pointers)
+    uint32_t *tab = nullptr, *cell = nullptr, *row = nullptr, *cnt = nullptr;
+    hipError_t e = hipMalloc(&tab, (size_t)cells * 4);
+    if (e == hipSuccess) e = hipMalloc(&cell, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&row, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&cnt, 4);
+    if (e == hipSuccess) e = hipMemsetAsync(tab, 0xFF, (size_t)cells * 4, s->stream);   // empty; k_unique_emit keeps it so
+    if (e != hipSuccess) {
+      (void)hipFree(tab); (void)hipFree(cell); (void)hipFree(row); (void)hipFree(cnt);
+      return fail(C4_ERR_HIP, std::string("c4_session_unique_leaves: ") + hipGetErrorString(e));
+    }
+    s->uniq_tab = tab; s->uniq_cell = cell; s->uniq_row = row; s->uniq_count = cnt;
     s->uniq_tab_mask = cells - 1;
   }
   hipLaunchKernelGGL(k_unique_insert, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->p.slots, s->p.leaf_models, n, s->uniq_tab,

@@ -22,8 +22,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 N_COLS, N_ROWS = 7, 6
-import os as _os
-_ABLATE_HEAD_OUT = _os.environ.get("C4_ABLATE_HEAD_OUT") == "1"
 
 
 @dataclass
@@ -132,7 +130,11 @@ class InferenceNet:
                        # GEMM is launched (session.capture_pair records / waits cross-stream events there)
 
     def __init__(self, model: ConnectFourNet, device: torch.device, dtype: torch.dtype = torch.bfloat16,
-                 hip_tower: Optional[bool] = None, gemm: Optional[str] = None, gemm_config: Optional[int] = None):
+                 hip_tower: Optional[bool] = None, gemm: Optional[str] = None, gemm_config=None, tower_config: int = 0):
+        """gemm: "hip" (the hand-written MFMA GEMM, default with the HIP tower) or "hipblaslt" (PyTorch's library GEMM, an
+        A/B switch: its low bits depend on the batch shape).  gemm_config: c4_linear_bf16's tile configuration, one number or
+        "wide,narrow" (the merged 2F-wide first layer, the F-wide layers); tower_config: c4_conv_tower_bf16's workgroup
+        shape; 0 / None = automatic.  Measurement switches are constructor arguments: nothing is read from the environment."""
         self.device = torch.device(device)
         self.dtype = dtype
         model = model.eval()
@@ -186,9 +188,8 @@ class InferenceNet:
         # Hidden layers of the heads: "hip" = the hand-written MFMA GEMM (c4_linear_bf16), whose result for
         # a position does not depend on the batch or the row it sits in -- the default wherever the HIP
         # tower runs; "hipblaslt" = PyTorch's library GEMM (kept for A/B timing: its low bits depend on
-        # the batch shape).  C4A0_GEMM / C4A0_GEMM_CONFIG override for experiments.
-        import os
-        gemm = gemm or os.environ.get("C4A0_GEMM") or ("hip" if self.hip_tower else "hipblaslt")
+        # the batch shape).
+        gemm = gemm or ("hip" if self.hip_tower else "hipblaslt")
         if gemm not in ("hip", "hipblaslt"):
             raise ValueError("gemm must be 'hip' or 'hipblaslt'")
         if gemm == "hip" and not (self.hip_tower and (42 * self.channels) % 192 == 0):
@@ -198,9 +199,9 @@ class InferenceNet:
         # not depend on the batch (session.narrow_if_worthwhile may then narrow whenever it likes)
         self.batch_invariant = self.hip_tower and gemm == "hip"
         # tile configuration: one number, or "wide,narrow" (the merged 2F-wide first layer, the F-wide layers); 0 = automatic
-        cfg = str(gemm_config if gemm_config is not None else os.environ.get("C4A0_GEMM_CONFIG", "0")).split(",")
+        cfg = str(gemm_config if gemm_config is not None else "0").split(",")
         self.gemm_config = (int(cfg[0]), int(cfg[-1]))
-        self.tower_config = int(os.environ.get("C4A0_TOWER_CONFIG", "0"))   # c4_conv_tower_bf16's config, 0 = automatic (tools/tower_ab.sh)
+        self.tower_config = int(tower_config)   # c4_conv_tower_bf16's config, 0 = automatic
         mv = lambda ts: [t.to(self.device, dtype).contiguous() for t in ts]
         self.conv_w = [w.to(self.device, dtype).contiguous(memory_format=torch.channels_last) for w in self.conv_w]
         self.conv_b = mv(self.conv_b)
@@ -263,7 +264,7 @@ class InferenceNet:
         for i, (w, b) in enumerate(pol_rest):
             p = self._linear_relu(p, w, b)
             if hook is not None:
-                hook(3 + i)      # after each narrow policy layer (session.capture_pair's phase experiments, C4_PAIR_OFFSET)
+                hook(3 + i)      # after each narrow policy layer (capture_pair's offset_stage)
         for w, b in val_rest:
             v = self._linear_relu(v, w, b)
         if self.hip_tower:
@@ -275,8 +276,6 @@ class InferenceNet:
             lp = out_logprobs if out_logprobs is not None else torch.empty((g, 7), dtype=torch.float32, device=self.device)
             q = out_q if out_q is not None else torch.empty((g, 2), dtype=torch.float32, device=self.device)
             assert p.stride(1) == 1 and v.stride(1) == 1
-            if _ABLATE_HEAD_OUT:   # timing experiment only: is the output kernel on the round's critical path?
-                return lp, q
             check(self._L.c4_head_out_bf16(C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()),
                                            C.c_void_p(self.pol_w[-1].data_ptr()), C.c_void_p(self.val_w[-1].data_ptr()),
                                            C.c_void_p(self.pol_b32.data_ptr()), C.c_void_p(self.val_b32.data_ptr()),
@@ -341,7 +340,8 @@ class GraphedEvaluator:
         torch.cuda.current_stream(planes.device).wait_stream(side)
         torch.cuda.synchronize(planes.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        from .session import CAPTURE_ERROR_MODE
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_ERROR_MODE):
             net.forward(planes, out_logprobs=logprobs, out_q=q)
 
     def __call__(self, _planes: torch.Tensor):

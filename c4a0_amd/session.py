@@ -20,6 +20,12 @@ from ._lib import C4Error, Config, Counters, GameMetadataC, SampleRec, check
 DeviceEvaluator = Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]
 """evaluator(planes[G,2,6,7]) -> (policy_logprobs[G,7] float32, q[G,2] float32) on the same device."""
 
+# Stream captures are opened in hipStreamCaptureModeThreadLocal: only THIS thread's calls are checked against the
+# open capture.  In the default (global) mode a capture-unsafe call from ANY thread -- RCCL's watchdog thread polls
+# its events with hipEventQuery for as long as a process group lives -- invalidates it, and a training loop calls
+# play_games_sharded with the group up and collectives just issued (DESIGN 5, tests/test_gpu_sharded.py).
+CAPTURE_ERROR_MODE = "thread_local"
+
 
 class DeviceSession:
     def __init__(self, n_slots: int, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float,
@@ -131,7 +137,7 @@ class DeviceSession:
         main.wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream):
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode=CAPTURE_ERROR_MODE):
             self.bind(torch.cuda.current_stream(self.device))
             for _ in range(steps_per_graph):
                 self.evaluate(evaluator)
@@ -224,9 +230,9 @@ class DeviceSession:
 
     NARROW_CHECK_ROUNDS = 64   # lock-step rounds between two looks at the tail (a stream synchronisation each)
 
-    def narrow_if_worthwhile(self, multiple: int = 256, asynchronous: bool = False) -> bool:
-        """Tail of a job: when every request has been started and at most half of the rows still hold
-        a game, compact() the session.  True if `self.rows` changed (captured graphs are then stale).
+    def wants_narrowing(self, multiple: int = 256, asynchronous: bool = False) -> bool:
+        """Tail of a job: True when every request has been started and at most half of the rows still
+        hold a game, i.e. compact() would pay.  Takes no action.
 
         asynchronous=False: the decision is taken from a SYNCHRONOUS read of the session's counters, and
         callers ask at fixed round counts (NARROW_CHECK_ROUNDS), so the step at which a session narrows
@@ -242,7 +248,13 @@ class DeviceSession:
         else:
             c = self.counters()                     # synchronises this session's stream
             done, started = c["games_done"], c["games_started"]
-        if started < self.n_games or (self.n_games - done) > self.rows // 2:
+        return started >= self.n_games and (self.n_games - done) <= self.rows // 2
+
+    def narrow_if_worthwhile(self, multiple: int = 256, asynchronous: bool = False) -> bool:
+        """wants_narrowing() -> compact().  True if `self.rows` changed (captured graphs are then stale).
+        Only for a session whose kernels all run on ITS bound stream (compact() waits for that stream alone);
+        sessions replayed from a shared graph on another stream go through session._run_pair."""
+        if not self.wants_narrowing(multiple, asynchronous):
             return False
         before = self.rows
         self.compact(multiple)
@@ -304,8 +316,8 @@ class DeviceSession:
         return steps
 
 
-def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cuda.Stream], evaluator, steps_per_graph: int = 32
-                 ) -> "torch.cuda.CUDAGraph":
+def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cuda.Stream], evaluator, steps_per_graph: int = 32,
+                 strict: bool = False, offset_stage: int = 1) -> "torch.cuda.CUDAGraph":
     """TWO sessions' rounds captured into ONE HIP graph with an explicit software pipeline between them.
 
     Two sessions that replay independent graphs on two streams settle into whatever relative phase the
@@ -318,7 +330,7 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
     [narrow layers, head outputs, step kernel]; for the rest of the replay the two streams run free from
     that phase, and the join at the graph's end re-aligns them.  Nothing else changes (same kernels, same
     per-session order, same samples).  Measured on one box (profiles/r03_pairing.txt): this 25.7 k games/s
-    every time; a hand-over in EVERY round (C4_PAIR_STRICT=1) 25.4-25.5 k; starting B after A's third GEMM
+    every time; a hand-over in EVERY round (strict=True) 25.4-25.5 k; starting B after A's third GEMM (offset_stage=4)
     instead 22.8 k (the bad phase, reproduced on purpose); two free-running graphs 26.1-26.2 k in four runs
     out of five and 24.3 k in the fifth (22.7 k on other boxes).  What the single graph buys is that the
     result no longer depends on a coin toss at start-up, for 1.6 % of the lucky case.
@@ -343,14 +355,13 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
     graph = torch.cuda.CUDAGraph()
     prev_hook = getattr(evaluator, "stage_hook", None)
     try:
-        with torch.cuda.graph(graph, stream=s0):
+        with torch.cuda.graph(graph, stream=s0, capture_error_mode=CAPTURE_ERROR_MODE):
             a.bind(s0)
             b.bind(s1)
             s1.wait_stream(s0)                                  # fork: s1 joins the capture
             ev_b_prev = None
-            import os
-            strict = os.environ.get("C4_PAIR_STRICT") == "1"    # A/B knob: hand-over in EVERY round instead of once per graph
-            offset_stage = int(os.environ.get("C4_PAIR_OFFSET", "1"))   # B starts when this stage of A's first round is done (1 = first hidden layer)
+            # strict: hand-over in EVERY round instead of once per graph; offset_stage: B starts when this stage of A's
+            # first round is done (1 = first hidden layer) -- measurement arguments (tools/), the defaults are the product
             for r in range(steps_per_graph):
                 ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
                 free = not strict
@@ -391,7 +402,7 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
 
 
 def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator, steps_per_graph: int = 8,
-                 max_chunks_in_flight: int = 2) -> List[int]:
+                 max_chunks_in_flight: int = 2, paired: Optional[bool] = None) -> List[int]:
     """Play the games of several sessions of one device to completion CONCURRENTLY, each session
     replaying its own HIP graph of (evaluator, step kernel) rounds on its own stream.
 
@@ -401,13 +412,13 @@ def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator
     kernels run under the other half's GEMMs.  A game's samples do not depend on which session or
     slot plays it.  `evaluator` must be pure device code writing into the bound tensors
     (graph_safe, e.g. c4a0_amd.nn.InferenceNet); it is shared (weights are read-only, activations
-    live in each graph's own pool).  Returns the steps each session ran."""
+    live in each graph's own pool).  paired: None = ONE explicitly pipelined graph (capture_pair) whenever two sessions
+    share an InferenceNet; False = independent graphs (A/B).  Returns the steps each session ran."""
     dev = sessions[0].device
     streams = [torch.cuda.Stream(device=dev) for _ in sessions]
     cur = torch.cuda.current_stream(dev)
     invariant = bool(getattr(evaluator, "batch_invariant", False))
-    import os
-    paired = len(sessions) == 2 and hasattr(evaluator, "stage_hook") and os.environ.get("C4_PAIR", "1") != "0"   # C4_PAIR=0: A/B knob
+    paired = len(sessions) == 2 and hasattr(evaluator, "stage_hook") and paired is not False
     graphs = []
     for s, st in zip(sessions, streams):
         st.wait_stream(cur)
@@ -482,11 +493,23 @@ def _run_pair(sessions, streams, evaluator, steps_per_graph, max_chunks_in_fligh
             break
         chunks += 1
         if chunks % max(1, sessions[0].NARROW_CHECK_ROUNDS // steps_per_graph) == 0:
-            narrowed = [s.narrow_if_worthwhile(asynchronous=invariant) for s in sessions]
-            if any(narrowed):   # the old graph carries the old widths
+            # Both sessions' kernels are nodes of ONE graph replayed on streams[0], and up to max_chunks_in_flight
+            # replays are still running here; compact() waits for its session's OWN stream only (B's is streams[1],
+            # on which nothing of the replay is visible).  So: decide first, for both, without touching the slots;
+            # if either wants to narrow, drain the device; only then move games (compacting B under a
+            # running replay corrupted its slots whenever B narrowed at a check where A did not).
+            if not invariant:
+                torch.cuda.synchronize(dev)          # the synchronous decision below must see every replayed round
+            wants = [s.wants_narrowing(asynchronous=invariant) for s in sessions]
+            if any(wants):
                 inflight.clear()
                 torch.cuda.synchronize(dev)
-                graph = capture_pair(sessions, streams, evaluator, steps_per_graph)
+                before = [s.rows for s in sessions]
+                for s, w in zip(sessions, wants):
+                    if w:
+                        s.compact()
+                if [s.rows for s in sessions] != before:   # the old graph carries the old widths
+                    graph = capture_pair(sessions, streams, evaluator, steps_per_graph)
     torch.cuda.synchronize(dev)
     for s in sessions:
         s.set_timing(True)

@@ -23,6 +23,12 @@
 extern "C" {
 #endif
 
+/* Version of THIS interface: bumped whenever a signature or a struct layout below changes (version 3 added `config` in the
+ * middle of c4_conv_tower_bf16's arguments).  A consumer compiled against this header checks it once at start-up --
+ * `if (c4_abi_version() != C4_ABI_VERSION) refuse` -- because the dynamic linker compares names, not signatures
+ * (tests/abi_consumer*.c and c4a0_amd/_lib.py do).  No reference counterpart: the reference's boundary is PyO3. */
+#define C4_ABI_VERSION 4
+
 #define C4_N_COLS 7          /* rust/src/c4r.rs:45, lib.rs:28 */
 #define C4_N_ROWS 6          /* rust/src/c4r.rs:44, lib.rs:29 */
 #define C4_BUF_N_CHANNELS 2  /* rust/src/c4r.rs:48, lib.rs:30 */
@@ -103,6 +109,7 @@ typedef struct {
 typedef struct c4_session c4_session;
 
 const char* c4_last_error_string(void);
+int c4_abi_version(void); /* == C4_ABI_VERSION of the header the library was compiled with */
 /* Content hash of the sources the library was compiled from (no reference counterpart: build
  * hygiene; c4a0_amd/csrc/build.py rebuilds, and c4a0_amd/_lib.py refuses, a stale library). */
 const char* c4_source_hash(void);

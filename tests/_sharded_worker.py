@@ -36,7 +36,28 @@ def main():
         device = "cuda:0"
     reqs = [GameMetadata(1000 + 7 * i, 0, 0) for i in range(n_games)]
     stats = {}
-    if mode == "net":        # the real bf16 4-block / 32-channel network (same weights on every rank: same seed)
+    extra = {}
+    if mode == "rccl_live":
+        # a training loop's use of the entry point: the process group has just run collectives on this device when the
+        # HIP graphs are captured (broadcast of every weight tensor, barrier), a collective follows, and the call is
+        # repeated in the same process -- RCCL's watchdog thread is alive (and polls events) during both captures
+        from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+        torch.manual_seed(1337)
+        net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 2, 2)), torch.device(device), dtype=torch.bfloat16)
+        n_coll = 0
+        for t in [net.tw0, net.tw, net.tbias, net.merged_w1, net.merged_b1] + net.pol_w + net.val_w:
+            dist.broadcast(t, src=0)
+            n_coll += 1
+        dist.barrier()
+        n_coll += 1
+        kw = dict(evaluator=net, device=device, resident_games=16, concurrent_sessions=2)
+        res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, stats=stats, **kw)
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        second = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, **kw)
+        extra = {"cbor_second_call": second.to_cbor(), "collectives_before_play": n_coll}
+    elif mode == "net":        # the real bf16 4-block / 32-channel network (same weights on every rank: same seed)
         from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
         torch.manual_seed(1337)
         net = InferenceNet(ConnectFourNet(ModelConfig(4, 32, 4, 2)), torch.device(device), dtype=torch.bfloat16)
@@ -48,7 +69,7 @@ def main():
         res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, evaluator=hash_eval_torch, device=device,
                                  resident_games=8, stats=stats)
     with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
-        pickle.dump({"cbor": res.to_cbor(), "allgather": stats["sample_allgather"], "games_done": stats.get("games_done")}, f)
+        pickle.dump({"cbor": res.to_cbor(), "allgather": stats["sample_allgather"], "games_done": stats.get("games_done"), **extra}, f)
     dist.barrier()
     dist.destroy_process_group()
 

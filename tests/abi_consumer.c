@@ -55,6 +55,10 @@ int main(int argc, char** argv) {
   const uint32_t n_slots = (uint32_t)strtoul(argv[2], NULL, 10), n_iter = (uint32_t)strtoul(argv[3], NULL, 10);
   const int device = argc > 4 ? atoi(argv[4]) : 0;
 
+  if (c4_abi_version() != C4_ABI_VERSION) {   /* the linker compares names, not signatures */
+    fprintf(stderr, "libc4a0_hip.so implements ABI %d, this host was compiled for %d\n", c4_abi_version(), C4_ABI_VERSION);
+    return 4;
+  }
   int n_dev = 0;
   C4(c4_device_count(&n_dev));
   if (n_dev <= device) {

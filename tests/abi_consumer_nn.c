@@ -74,6 +74,10 @@ int main(int argc, char** argv) {
   }
   const uint64_t n_games = strtoull(argv[2], NULL, 10);
   const uint32_t G = (uint32_t)strtoul(argv[3], NULL, 10), n_iter = (uint32_t)strtoul(argv[4], NULL, 10);
+  if (c4_abi_version() != C4_ABI_VERSION) {   /* the linker compares names, not signatures */
+    fprintf(stderr, "libc4a0_hip.so implements ABI %d, this host was compiled for %d\n", c4_abi_version(), C4_ABI_VERSION);
+    return 4;
+  }
   HIP(hipSetDevice(0));
 
   FILE* f = fopen(argv[1], "rb");

@@ -320,6 +320,48 @@ def test_play_games_narrows_the_tail_without_changing_samples():
     assert st_wide["rows_at_end"] < 1024 and st_small["rows_at_end"] == 128
 
 
+@pytest.mark.parametrize("n_a,n_b", [(900, 300), (300, 900)])
+def test_paired_sessions_of_unequal_size_narrow_at_different_checks(n_a, n_b):
+    """the two sessions of the paired graph (session._run_pair) reach their narrowing thresholds at
+    DIFFERENT checks when they hold different numbers of games; the one that narrows must not be compacted under
+    a replay of the shared graph that is still running.  Samples must equal a run that never narrows."""
+    import c4a0_amd
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+    from c4a0_amd.session import DeviceSession, run_sessions
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 2, 2)), dev, dtype=torch.bfloat16)
+    ids_a, ids_b = [(20000 + i, 0, 0) for i in range(n_a)], [(30000 + i, 0, 0) for i in range(n_b)]
+    sessions = []
+    for ids in (ids_a, ids_b):
+        s = DeviceSession(len(ids), 6, 6.6, 0.01, device=dev, planes_dtype=torch.bfloat16)
+        s.set_games(ids)
+        sessions.append(s)
+    rows_seen = []
+    orig = DeviceSession.compact
+
+    def spy(self, multiple=256):
+        out = orig(self, multiple)
+        rows_seen.append((sessions.index(self), self.rows))
+        return out
+
+    DeviceSession.compact = spy
+    try:
+        run_sessions(sessions, net, steps_per_graph=8)
+    finally:
+        DeviceSession.compact = orig
+    got = [s.drain_samples() for s in sessions]
+    for s in sessions:
+        s.close()
+    # both narrowed, and at least once one narrowed alone (a check at which the other kept its width)
+    assert {i for i, _ in rows_seen} == {0, 1}, rows_seen
+    want = c4a0_amd.play_games([c4a0_amd.GameMetadata(*r) for r in ids_a + ids_b], 64, 6, 6.6, 0.01, evaluator=net,
+                               resident_games=128, concurrent_sessions=1)
+    want_recs, _ = want.to_records()
+    assert np.concatenate(got).tobytes() == want_recs.tobytes()
+
+
 def test_search_width_beyond_the_arena_limit_is_refused_with_a_reason():
     """beyond n_mcts_iterations = 1523 the provable worst case (43 n + 8 blocks per game)
     no longer fits the 16-bit child links: the session refuses the default sizing at creation instead

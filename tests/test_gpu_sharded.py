@@ -124,110 +124,10 @@ def test_bench_over_rccl_at_world_size_one(tmp_path):
     _check_bench_line(r, 1)
 
 
-def _assert_equals_oracle(result, reqs, n_iter):
-    """every sample of every game -- position, policy bits, both q bits -- is the oracle's"""
-    import numpy as np
-    from oracle import c4oracle as O
-    from tests.helpers import oracle_samples_by_game
-
-    ora, _ = O.self_play([(r.game_id, 0, 0) for r in reqs], 64, n_iter, 6.6, 0.01, "hash")
-    ob = oracle_samples_by_game(ora)
-    assert len(result.results) == len(reqs)
-    for g in result.results:
-        mine = [(s.mask, s.value, np.asarray(s.policy, dtype=np.float32).tobytes(), np.float32(s.q_penalty).tobytes(),
-                 np.float32(s.q_no_penalty).tobytes()) for s in g.samples]
-        assert mine == ob[g.metadata.game_id], f"game {g.metadata.game_id}"
-
-
-@pytest.mark.parametrize("mode,n_games,n_iter", [("eager", 37, 12), ("graph2", 64, 20)])
-def test_rccl_world_size_one_equals_play_games(tmp_path, mode, n_games, n_iter):
-    """The product path over the REAL backend ("nccl" = RCCL): device pack -> RCCL all_gather_into_tensor
-    of counts and records -> device merge.  RCCL takes one rank per device, so on the one-GPU box the
-    world has one rank; the collectives, buffers and merge are the ones an 8-GPU job runs."""
-    port = str(_free_port())
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_sharded_worker.py"), "0", "1", port, str(tmp_path),
-                          str(n_games), str(n_iter), mode, "nccl"], env=env, cwd=ROOT)
-    from c4a0_amd import GameMetadata, play_games
-    from tests.helpers import hash_eval_torch
-
-    reqs = [GameMetadata(1000 + 7 * i, 0, 0) for i in range(n_games)]
-    single = play_games(reqs, 64, n_iter, 6.6, 0.01, evaluator=hash_eval_torch, device="cuda:0", resident_games=16)
-    assert p.wait(timeout=600) == 0
-    got = pickle.load(open(tmp_path / "rank0.pkl", "rb"))
-    assert got["allgather"]["backend"] == "nccl"
-    assert got["cbor"] == single.to_cbor()
-    _assert_equals_oracle(single, reqs, n_iter)
-
-
-def _check_bench_line(r, n_gpus):
-    import json
-
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == n_gpus and out["scaling"] == "weak" and out["value"] > 0
-    ag = out["sample_allgather"]
-    assert "error" not in ag, ag
-    assert ag["merged_in_request_order_and_complete"] is True and ag["games_merged"] > 0 and ag["ms"] > 0
-    assert len(ag["records_per_rank"]) == n_gpus and min(ag["records_per_rank"]) > 0
-    assert len(out["per_rank"]["games_completed"]) == n_gpus and len(out["per_rank"]["elapsed_s"]) == n_gpus
-    return out
-
-
-def test_bench_starts_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2` with NO launcher: bench.py starts the two rank processes itself (fresh
-    children, before any GPU call), relays the one JSON line and the exit code.  Two ranks share the one
-    GPU of the test box, hence gloo."""
-    env = dict(os.environ, C4_BENCH_SAME_DEVICE="1", C4_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--rounds-per-step", "128",
-           "--preroll", "1600"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    out = _check_bench_line(r, 2)
-    assert "cpu_baseline" not in out
-
-
-def test_bench_over_rccl_at_world_size_one(tmp_path):
-    """bench.py's N > 1 branch (barriers, reductions, the sample exchange and its check) over backend
-    "nccl" = RCCL, forced on at world size 1 (C4_BENCH_FORCE_DIST): what the 8-GPU node will run, minus peers."""
-    env = dict(os.environ, C4_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "C4_BENCH_BACKEND", "C4_BENCH_SAME_DEVICE"):
-        env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--rounds-per-step", "128",
-           "--preroll", "1600", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    _check_bench_line(r, 1)
-
-
 def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     """bench.py's N > 1 code path (ids sharded rank + W i, barriers, max-over-ranks timing, the sample
-    exchange and its completeness check) with two ranks that share the one GPU: launched exactly as the
-    driver launches it, except for the backend (gloo: RCCL refuses two ranks on one device)."""
-    import json
-
-    env = dict(os.environ, C4_BENCH_SAME_DEVICE="1", C4_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--rounds-per-step", "128", "--preroll", "1600"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert "cpu_baseline" not in out                                  # rank 0 at N = 1 only
-    ag = out["sample_allgather"]
-    assert "error" not in ag, ag
-    assert ag["merged_in_request_order_and_complete"] is True and ag["games_merged"] > 0
-    assert len(ag["records_per_rank"]) == 2 and min(ag["records_per_rank"]) > 0
-
-
-def test_bench_multi_rank_path_on_one_gpu(tmp_path):
-    """bench.py's N > 1 code path launched exactly as the driver launches it (torch.distributed.run), except
-    for the backend (gloo: RCCL refuses two ranks on one device)."""
+    exchange and its completeness check) launched exactly as the driver launches it (torch.distributed.run),
+    except for the backend (gloo: RCCL refuses two ranks on one device)."""
     env = dict(os.environ, C4_BENCH_SAME_DEVICE="1", C4_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
@@ -235,3 +135,30 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     out = _check_bench_line(r, 2)
     assert "cpu_baseline" not in out                                  # rank 0 at N = 1 only
+
+
+def test_rccl_live_during_graph_capture_collective_before_play_and_two_calls(tmp_path):
+    """the way a training loop uses the sharded entry point.  The RCCL process group is up
+    and has just run collectives (a broadcast of every weight tensor from rank 0, a barrier) when
+    `play_games_sharded` captures its HIP graphs (two sessions, the paired graph of session.capture_pair, with
+    the bf16 network); another collective follows; then `play_games_sharded` is called AGAIN in the same
+    process (fresh sessions, fresh capture, RCCL's watchdog thread polling its events all along).  Both calls
+    must return the single-process result byte for byte."""
+    port = str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    n_games, n_iter = 96, 12
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_sharded_worker.py"), "0", "1", port, str(tmp_path),
+                          str(n_games), str(n_iter), "rccl_live", "nccl"], env=env, cwd=ROOT)
+    import torch
+    from c4a0_amd import GameMetadata, play_games
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    torch.manual_seed(1337)
+    net = InferenceNet(ConnectFourNet(ModelConfig(1, 32, 2, 2)), torch.device("cuda:0"), dtype=torch.bfloat16)
+    reqs = [GameMetadata(1000 + 7 * i, 0, 0) for i in range(n_games)]
+    single = play_games(reqs, 64, n_iter, 6.6, 0.01, evaluator=net, device="cuda:0", resident_games=16, concurrent_sessions=1)
+    assert p.wait(timeout=600) == 0
+    got = pickle.load(open(tmp_path / "rank0.pkl", "rb"))
+    assert got["allgather"]["backend"] == "nccl" and got["collectives_before_play"] >= 2
+    assert got["cbor"] == single.to_cbor(), "first call (right after a broadcast + barrier) differs"
+    assert got["cbor_second_call"] == single.to_cbor(), "second call in the same process differs"

@@ -53,6 +53,29 @@ def test_bn_folded_f32_inference_matches_reference_outputs():
     assert torch.equal(out_lp, lp) and torch.equal(out_q, q)
 
 
+def test_restatement_matches_the_reference_at_the_hip_kernels_width():
+    """tests/golden/nn_fixture_1x32.npz: outputs of the reference's nn.py for a 1-block / 32-channel net with 2 policy /
+    2 value layers whose weights are a closed-form function of (tensor name, index) -- the width the HIP kernels
+    accept, so tests/test_gpu_nn.py can compare them with the reference itself.  Here: the f32 restatement, 1e-5."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from closed_form_weights import fill_closed_form
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "nn_fixture_1x32.npz"))
+    assert [int(v) for v in z["cfg"]] == [1, 32, 2, 2]
+    model = ConnectFourNet(ModelConfig(*[int(v) for v in z["cfg"]])).eval()
+    with torch.no_grad():
+        fill_closed_form(model)
+        lp, qp, qn = model(torch.from_numpy(z["x"]))
+    assert np.abs(lp.numpy() - z["policy_logprobs"]).max() <= TOL
+    assert np.abs(qp.numpy() - z["q_penalty"]).max() <= TOL and np.abs(qn.numpy() - z["q_no_penalty"]).max() <= TOL
+    net = InferenceNet(model, torch.device("cpu"), dtype=torch.float32)   # BN folded
+    lp2, q2 = net(torch.from_numpy(z["x"]))
+    assert np.abs(lp2.numpy() - z["policy_logprobs"]).max() <= TOL and np.abs(q2[:, 0].numpy() - z["q_penalty"]).max() <= TOL
+    # the outputs are informative (not saturated, not uniform): the comparison on the GPU means something
+    assert 0.1 < z["policy_logprobs"].std(0).min() and np.abs(z["q_penalty"]).max() < 0.999
+
+
 def test_flops_per_leaf_matches_survey():
     # SURVEY 8d: 1x32 16.1 M; 4x32 20.7 M; 8x64 107.5 M
     assert round(flops_per_leaf(ModelConfig(1, 32, 4, 2)) / 1e6, 1) == 16.1

@@ -10,7 +10,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$c
 done
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --independent-graphs > $O/bench_independent_graphs.json 2>/dev/null
-C4A0_GEMM=hipblaslt python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_hipblaslt.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --gemm hipblaslt > $O/bench_hipblaslt.json 2>/dev/null
 python bench.py --whole-job > $O/whole_job.json 2> $O/whole_job.err
 python tools/tree_roofline.py --games 2048,4096,16384,65536,131072 > $O/tree_sweep.json 2> $O/tree_sweep.err
 bash tools/tower_ab.sh "2048 4096" > $O/tower.txt 2>&1

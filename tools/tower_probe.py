@@ -7,8 +7,9 @@ dev = torch.device("cuda:0")
 ch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+tower_config = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # c4_conv_tower_bf16's workgroup shape, 0 = automatic
 torch.manual_seed(0)
-net = InferenceNet(ConnectFourNet(ModelConfig(blocks, ch, 4, 2)), dev)
+net = InferenceNet(ConnectFourNet(ModelConfig(blocks, ch, 4, 2)), dev, tower_config=tower_config)
 x = (torch.rand(n, 2, 6, 7, device=dev) > 0.7).to(torch.bfloat16)
 for _ in range(5):
     net.tower(x)
