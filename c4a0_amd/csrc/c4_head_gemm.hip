@@ -46,12 +46,96 @@ struct GemmParams {
   const float* bias;     // [N]
   uint16_t* y;           // [M][ldy]
   uint32_t M, N, K, ldx, ldy, relu;
-  uint32_t tiles_m, tiles_n;
-  uint32_t xm, xn;       // XCD rectangle grid (xm * xn == 8), 0 = plain row-major tile order
+  // tile of block b (host-computed, launch_common): xcd = b & xcd_mask, idx = b >> xcd_shift,
+  //   tm = (xcd >> xn_log2) * rm + idx / rn,  tn = (xcd & ((1 << xn_log2) - 1)) * rn + idx % rn
+  // (idx / rn as a multiplication by rn_magic).  XCD rectangles: xcd_mask 7, xcd_shift 3; plain row-major order: 0, 0, rn = tiles_n.
+  uint32_t xcd_mask, xcd_shift, xn_log2, rm, rn, rn_magic;
 };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+#ifdef C4_PHASE_STAMPS
+// Diagnostic build only (tools/clock_probe.py): (a) the shader clock a GEMM's main loop actually ran at -- shader cycles
+// (s_memtime) over constant 100 MHz ticks (s_memrealtime) -- and (b) where a workgroup's time goes: stamps 0 entry,
+// 1 prologue issued, 2 first k-tile landed (first barrier passed), 3 main loop done, 4 tail DMA drained, 5 bias arrived,
+// 6 stores issued, 7 stores acknowledged; summed over the first wavefront of every workgroup, plus the earliest entry
+// and the latest exit of all workgroups since the last reset.
+__device__ unsigned long long c4_gemm_clk[16];   // {cycles, ticks, workgroups, -, phase ticks [7], -, min entry, max exit}
+#define C4_CLK_DECL() unsigned long long clk_ts[8]; unsigned long long clk_c0 = 0, clk_c1 = 0
+#define C4_GSTAMP(i) do { clk_ts[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define C4_CLK_BEGIN() do { clk_c0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define C4_CLK_END() do { clk_c1 = __builtin_amdgcn_s_memtime(); } while (0)
+#define C4_CLK_FLUSH()                                                                                       \
+  do {                                                                                                       \
+    if (threadIdx.x == 0) {                                                                                  \
+      atomicAdd(&c4_gemm_clk[0], clk_c1 - clk_c0);                                                           \
+      atomicAdd(&c4_gemm_clk[1], clk_ts[3] - clk_ts[1]);                                                     \
+      atomicAdd(&c4_gemm_clk[2], 1ull);                                                                      \
+      for (int i_ = 0; i_ < 7; i_++) atomicAdd(&c4_gemm_clk[4 + i_], clk_ts[i_ + 1] - clk_ts[i_]);           \
+      atomicMin(&c4_gemm_clk[12], clk_ts[0]);                                                                \
+      atomicMax(&c4_gemm_clk[13], clk_ts[7]);                                                                \
+    }                                                                                                        \
+  } while (0)
+#else
+#define C4_CLK_DECL() do { } while (0)
+#define C4_GSTAMP(i) do { } while (0)
+#define C4_CLK_BEGIN() do { } while (0)
+#define C4_CLK_END() do { } while (0)
+#define C4_CLK_FLUSH() do { } while (0)
+#endif
+
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- epilogue shared by both kernels.  The MFMA leaves a lane with 4 consecutive output features of one board (C/D map:
+// row = 4 (lane >> 4) + reg, col = lane & 15), i.e. 8 bytes of bf16; stored like that, a wavefront needs TM x TN store
+// instructions of 8 bytes per lane, and a launch's last microsecond is their ISSUE (measured with the phase stamps of
+// the diagnostic build: 1.3 us of a 15.8 us workgroup).  Two 16-row tiles of the same features are therefore exchanged
+// between the 16-lane rows of the wavefront (v_permlane16_swap_b32: odd rows of one register <-> even rows of the other),
+// after which every lane holds 8 consecutive features = 16 bytes of ONE board: half the store instructions, twice the
+// bytes per row segment.  Values are untouched (a permutation of registers): same bits as the 8-byte form.
+// (Write-through `sc1` stores, so that the launch leaves no dirty lines for its end-of-kernel write-back, measured
+// 2.4 % SLOWER in the bench, same box: plain stores stay.)
+template <int TM, int TN>
+__device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[TN][TM], const f32x4 (&bias_v)[TN], const GemmParams& p, int m_wave0, int n_wave0,
+                                                int li, int lg) {
+  const bool relu = p.relu != 0;
+  auto finish = [&](const f32x4& a, const f32x4& bv) __attribute__((always_inline)) {
+    f32x4 v = a + bv;
+    if (relu) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+    }
+    return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4));
+  };
+  // 16-byte stores: this lane writes board m16 + 32 pb, features n16 + 16 a .. + 7
+  const int m16 = m_wave0 + 16 * (lg & 1) + li;
+  uint16_t* y16 = p.y + (size_t)m16 * p.ldy + (n_wave0 + 8 * (lg >> 1));
+  const size_t pair_step = (size_t)32 * p.ldy;
+#pragma unroll
+  for (int pb = 0; pb < TM / 2; pb++) {
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+      const uint2 o0 = finish(acc[a][2 * pb], bias_v[a]), o1 = finish(acc[a][2 * pb + 1], bias_v[a]);
+      const auto sx = __builtin_amdgcn_permlane16_swap(o0.x, o1.x, false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(o0.y, o1.y, false, false);
+      const u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
+      if (m16 + 32 * pb < (int)p.M) {
+        *reinterpret_cast<u32x4*>(y16 + a * 16) = v;
+      }
+    }
+    y16 += pair_step;
+  }
+  if (TM & 1) {   // an odd tile left over (48-row wavefront tiles): 8 bytes per lane as the MFMA left them
+    const int m8 = m_wave0 + 16 * (TM - 1) + li;
+    uint16_t* y8 = p.y + (size_t)m8 * p.ldy + (n_wave0 + 4 * lg);
+    if (m8 < (int)p.M) {
+#pragma unroll
+      for (int a = 0; a < TN; a++) *reinterpret_cast<uint2*>(y8 + a * 16) = finish(acc[a][TM - 1], bias_v[a]);
+    }
+  }
+}
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmParams p) {
@@ -64,6 +148,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmPa
   static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "wave tiles are multiples of 16");
   static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+  C4_CLK_DECL();
+  C4_GSTAMP(0);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,19 +158,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmPa
 
   // ---- which tile: blocks b and b + 8 share an XCD (round-robin dispatch; speed only).  Give each
   // XCD a rectangle of tiles so that its private L2 sees each X row block and W column block once.
-  int tm, tn;
-  {
-    const int b = blockIdx.x;
-    if (p.xm) {
-      const int rm = p.tiles_m / p.xm, rn = p.tiles_n / p.xn;
-      const int xcd = b & 7, idx = b >> 3;
-      tm = (xcd / (int)p.xn) * rm + idx / rn;
-      tn = (xcd % (int)p.xn) * rn + idx % rn;
-    } else {
-      tm = b / (int)p.tiles_n;
-      tn = b % (int)p.tiles_n;
-    }
-  }
+  // (One straight-line formula, no division: the kernel's arguments are fetched by one scalar load at its top.)
+  const uint32_t blk = blockIdx.x, xcd = blk & p.xcd_mask, idx = blk >> p.xcd_shift;
+  const uint32_t qn = __umulhi(idx, p.rn_magic);                // idx / rn
+  const int tm = (int)((xcd >> p.xn_log2) * p.rm + qn);
+  const int tn = (int)((xcd & ((1u << p.xn_log2) - 1u)) * p.rn + (idx - qn * p.rn));
   const int tm0 = tm * BM, tn0 = tn * BN;
 
   // ---- DMA source offsets (bytes from x / w) of this lane for its L pieces of a k-tile; a k-tile
@@ -113,11 +191,19 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmPa
   // reading beyond the allocation
   const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((p.M - 1) * p.ldx + p.K) * 2u), 0x00020000);
   const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(p.N * p.K * 2u), 0x00020000);
+  // Pieces are issued for every kt, also past the last k-tile (so that the count of outstanding pieces is the same in
+  // every iteration: no branch around an issue, no tail cases in the counted waits) -- but those carry bit 31 in their
+  // per-lane offset: beyond num_records (both operands are < 2 GiB), so the bounds check answers them with zeros
+  // WITHOUT a memory access.  (The k-tile's own offset travels in the scalar offset, which the bounds check ignores:
+  // without the flag the tail pieces really read two k-tiles past the operands' rows -- 10 % more L2 traffic, a wait
+  // for them in front of the epilogue, and for the last row of a column view bytes beyond the allocation)
+  const int KT = (int)p.K / BK;
   auto issue_one = [&](int kt, int i) __attribute__((always_inline)) {
     uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
     const int c = wave + kWaves * i;
+    const uint32_t tail = kt >= KT ? 0x80000000u : 0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds((c < BM / 8) ? x_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)(st + c * 1024), 16,
-                                             (int)src_off[i], kt * (BK * 2), 0, 0);
+                                             (int)(src_off[i] | tail), kt * (BK * 2), 0, 0);
   };
   auto issue = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
@@ -136,18 +222,23 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmPa
   const uint32_t x_base = (uint32_t)(wm * (BM / WM)) * 128u;
   const uint32_t w_base = (uint32_t)(BM * BK * 2) + (uint32_t)(wn * (BN / WN)) * 128u;
 
-  const int KT = (int)p.K / BK;
+  // this wavefront's biases: requested now, used after the last k-tile (the epilogue used to open with this round trip)
+  f32x4 bias_v[TN];
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; s++)
-    if (s < KT) issue(s);
+  for (int a = 0; a < TN; a++) bias_v[a] = *reinterpret_cast<const f32x4*>(p.bias + tn0 + wn * (BN / WN) + a * 16 + 4 * lg);
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; s++) issue(s);
 
+  C4_GSTAMP(1);
+  C4_CLK_BEGIN();
   for (int kt = 0; kt < KT; kt++) {
-    // k-tile kt must have landed; the NSTAGE - 2 younger ones stay in flight.  (Pieces are issued for
-    // every kt, also past the last k-tile -- into a stage nobody reads again, within the operands'
-    // buffer bounds -- so the count of outstanding pieces is the same in every iteration: no branch
-    // around an issue, no tail cases in the wait.)
+    // k-tile kt must have landed; the NSTAGE - 2 younger ones stay in flight (the same count in every iteration:
+    // see issue_one for the pieces past the last k-tile)
     wait_vmcnt<(NSTAGE - 2) * L>();
     __builtin_amdgcn_s_barrier();                               // everybody's pieces of kt landed; everybody left buffer (kt - 1) % NSTAGE
+#ifdef C4_PHASE_STAMPS
+    if (kt == 0) C4_GSTAMP(2);
+#endif
     // The DMA pieces of k-tile kt + NSTAGE - 1 are NOT issued here in one burst (a wavefront would spend
     // hundreds of cycles queueing 1 KB requests before its first MFMA): they are handed out between the
     // MFMA groups below, one or two at a time, so the address pipe works under the matrix pipe.  With two
@@ -198,24 +289,24 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmPa
     }
   }
 
+  C4_CLK_END();
+  C4_GSTAMP(3);
   wait_vmcnt<0>();   // the pieces issued past the last k-tile must not land in an LDS allocation that was given away
+  C4_GSTAMP(4);
   // ---- epilogue: lane holds features n0 + 4 lg + {0..3} of board m (C/D map: row = 4 (lane >> 4) + reg, col = lane & 15)
+  // hipcc's wait-count pass does not see through the inline-asm wait above: it still believes the bias loads of the
+  // prologue to be in flight and would wait for them (in order, i.e. also for the STORES issued meanwhile) in the
+  // middle of the epilogue.  Using the values here puts its waits where everything has long arrived.
 #pragma unroll
-  for (int a = 0; a < TN; a++) {
-    const int n = tn0 + wn * (BN / WN) + a * 16 + 4 * lg;
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-    for (int b = 0; b < TM; b++) {
-      const int m = tm0 + wm * (BM / WM) + b * 16 + li;
-      f32x4 v = acc[a][b] + bv;
-      if (p.relu) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
-      }
-      const bf16x4 o = __builtin_convertvector(v, bf16x4);
-      if (m < (int)p.M) *reinterpret_cast<uint2*>(p.y + (size_t)m * p.ldy + n) = __builtin_bit_cast(uint2, o);
-    }
-  }
+  for (int a = 0; a < TN; a++) asm volatile("" ::"v"(bias_v[a]));
+  C4_GSTAMP(5);
+  store_wave_tile<TM, TN>(acc, bias_v, p, tm0 + wm * (BM / WM), tn0 + wn * (BN / WN), li, lg);
+  C4_GSTAMP(6);
+#ifdef C4_PHASE_STAMPS
+  wait_vmcnt<0>();
+  C4_GSTAMP(7);
+  C4_CLK_FLUSH();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -241,7 +332,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void c4_head_gemm32_kernel(GemmPar
   constexpr int kChunks = (BM + BN) / 16;                     // 1 KB pieces (16 rows x 64 bytes) per k-tile
   constexpr int L = (kChunks + kWaves - 1) / kWaves;          // pieces of the wavefronts that issue the most
   constexpr int R = kChunks % kWaves;                         // wavefronts 0 .. R - 1 issue L, the others L - 1 (R == 0: all L)
-  static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && NSTAGE >= 3 && NSTAGE <= 4, "tile / ring");
+  static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && NSTAGE >= 3 && NSTAGE <= 5, "tile / ring");
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -250,19 +341,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void c4_head_gemm32_kernel(GemmPar
   const int li = lane & 15, lg = lane >> 4;
   const bool short_wave = R != 0 && wave >= R;                // issues L - 1 pieces per k-tile
 
-  int tm, tn;
-  {
-    const int b = blockIdx.x;
-    if (p.xm) {
-      const int rm = p.tiles_m / p.xm, rn = p.tiles_n / p.xn;
-      const int xcd = b & 7, idx = b >> 3;
-      tm = (xcd / (int)p.xn) * rm + idx / rn;
-      tn = (xcd % (int)p.xn) * rn + idx % rn;
-    } else {
-      tm = b / (int)p.tiles_n;
-      tn = b % (int)p.tiles_n;
-    }
-  }
+  const uint32_t blk = blockIdx.x, xcd = blk & p.xcd_mask, idx = blk >> p.xcd_shift;
+  const uint32_t qn = __umulhi(idx, p.rn_magic);                // idx / rn
+  const int tm = (int)((xcd >> p.xn_log2) * p.rm + qn);
+  const int tn = (int)((xcd & ((1u << p.xn_log2) - 1u)) * p.rn + (idx - qn * p.rn));
   const int tm0 = tm * BM, tn0 = tn * BN;
 
   auto swz = [](int row) __attribute__((always_inline)) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; };   // T = {0, 2, 3, 1}
@@ -284,12 +366,14 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void c4_head_gemm32_kernel(GemmPar
   }
   const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((p.M - 1) * p.ldx + p.K) * 2u), 0x00020000);   // see above
   const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(p.N * p.K * 2u), 0x00020000);
+  const int KT = (int)p.K / BKT;
   auto issue_one = [&](int kt, int i) __attribute__((always_inline)) {
     if (i == L - 1 && short_wave) return;
     uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
     const int c = wave + kWaves * i;
+    const uint32_t tail = kt >= KT ? 0x80000000u : 0u;          // past the last k-tile: out of bounds, answered with zeros without a memory access
     __builtin_amdgcn_raw_ptr_buffer_load_lds((c < BM / 16) ? x_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)(st + c * 1024), 16,
-                                             (int)src_off[i], kt * (BKT * 2), 0, 0);
+                                             (int)(src_off[i] | tail), kt * (BKT * 2), 0, 0);
   };
   auto wait_tile = [&]() __attribute__((always_inline)) {     // all but the (NSTAGE - 2) youngest k-tiles of THIS wavefront have landed
     if (short_wave) wait_vmcnt<(NSTAGE - 2) * (L - 1)>(); else wait_vmcnt<(NSTAGE - 2) * L>();
@@ -308,7 +392,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void c4_head_gemm32_kernel(GemmPar
   const uint32_t x_base = (uint32_t)(wm * (BM / WM)) * 64u;
   const uint32_t w_base = (uint32_t)(BM * BKT * 2) + (uint32_t)(wn * (BN / WN)) * 64u;
 
-  const int KT = (int)p.K / BKT;
+  f32x4 bias_v[TN];
+#pragma unroll
+  for (int a = 0; a < TN; a++) bias_v[a] = *reinterpret_cast<const f32x4*>(p.bias + tn0 + wn * (BN / WN) + a * 16 + 4 * lg);
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; s++) {
 #pragma unroll
@@ -353,21 +439,23 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void c4_head_gemm32_kernel(GemmPar
   wait_vmcnt<0>();
 
 #pragma unroll
-  for (int a = 0; a < TN; a++) {
-    const int n = tn0 + wn * (BN / WN) + a * 16 + 4 * lg;
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-    for (int b = 0; b < TM; b++) {
-      const int m = tm0 + wm * (BM / WM) + b * 16 + li;
-      f32x4 v = acc[a][b] + bv;
-      if (p.relu) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
-      }
-      const bf16x4 o = __builtin_convertvector(v, bf16x4);
-      if (m < (int)p.M) *reinterpret_cast<uint2*>(p.y + (size_t)m * p.ldy + n) = __builtin_bit_cast(uint2, o);
-    }
+  for (int a = 0; a < TN; a++) asm volatile("" ::"v"(bias_v[a]));   // see c4_head_gemm_kernel
+  store_wave_tile<TM, TN>(acc, bias_v, p, tm0 + wm * (BM / WM), tn0 + wn * (BN / WN), li, lg);
+}
+
+// Tile order: of the factorizations xm * xn = 8 that divide the tile grid, the one whose rectangle pulls the fewest
+// operand rows into an XCD's L2; none -> plain row-major order.
+inline uint32_t set_tile_order(GemmParams& p, uint32_t tiles_m, uint32_t tiles_n, uint32_t bm, uint32_t bn) {
+  p.xcd_mask = 0; p.xcd_shift = 0; p.xn_log2 = 0; p.rm = tiles_m; p.rn = tiles_n;
+  uint64_t best = ~0ull;
+  for (uint32_t xm = 1, l2 = 3; xm <= 8; xm *= 2, l2--) {
+    const uint32_t xn = 8 / xm;
+    if (tiles_m % xm || tiles_n % xn) continue;
+    const uint64_t rows = (uint64_t)(tiles_m / xm) * bm + (uint64_t)(tiles_n / xn) * bn;
+    if (rows < best) { best = rows; p.xcd_mask = 7; p.xcd_shift = 3; p.xn_log2 = l2; p.rm = tiles_m / xm; p.rn = tiles_n / xn; }
   }
+  p.rn_magic = (uint32_t)((1ull << 32) / p.rn + 1);            // exact for idx * rn < 2^32
+  return tiles_m * tiles_n;
 }
 
 template <int BM, int BN, typename K>
@@ -376,17 +464,8 @@ int launch_common(K k, GemmParams p, int threads, int lds_bytes, hipStream_t str
     const hipError_t e = c4host::opt_in_lds((const void*)k, lds_bytes, device);
     if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16: LDS opt-in: ") + hipGetErrorString(e));
   }
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = p.N / BN;
-  p.xm = p.xn = 0;
-  uint64_t best = ~0ull;
-  for (uint32_t xm = 1; xm <= 8; xm *= 2) {
-    const uint32_t xn = 8 / xm;
-    if (p.tiles_m % xm || p.tiles_n % xn) continue;
-    const uint64_t rows = (uint64_t)(p.tiles_m / xm) * BM + (uint64_t)(p.tiles_n / xn) * BN;
-    if (rows < best) { best = rows; p.xm = xm; p.xn = xn; }
-  }
-  k<<<dim3(p.tiles_m * p.tiles_n), dim3(threads), lds_bytes, stream>>>(p);
+  const uint32_t tiles = set_tile_order(p, (p.M + BM - 1) / BM, p.N / BN, BM, BN);
+  k<<<dim3(tiles), dim3(threads), lds_bytes, stream>>>(p);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16 launch: ") + hipGetErrorString(e));
   return C4_OK;
@@ -399,44 +478,47 @@ int launch_gemm32(GemmParams p, hipStream_t stream, int device) {
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW>
 int launch_gemm(GemmParams p, hipStream_t stream, int device) {
-  constexpr int kLds = NSTAGE * (BM + BN) * BK * 2;
-  auto k = c4_head_gemm_kernel<BM, BN, WM, WN, NSTAGE, MINW>;
-  if (kLds > 64 * 1024) {
-    const hipError_t e = c4host::opt_in_lds((const void*)k, kLds, device);
-    if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16: LDS opt-in: ") + hipGetErrorString(e));
-  }
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = p.N / BN;
-  // XCD rectangles: of the factorizations of 8 that divide the tile grid, the one whose rectangle
-  // pulls the fewest operand rows into an XCD's L2
-  p.xm = p.xn = 0;
-  uint64_t best = ~0ull;
-  for (uint32_t xm = 1; xm <= 8; xm *= 2) {
-    const uint32_t xn = 8 / xm;
-    if (p.tiles_m % xm || p.tiles_n % xn) continue;
-    const uint64_t rows = (uint64_t)(p.tiles_m / xm) * BM + (uint64_t)(p.tiles_n / xn) * BN;
-    if (rows < best) { best = rows; p.xm = xm; p.xn = xn; }
-  }
-  k<<<dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), kLds, stream>>>(p);
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16 launch: ") + hipGetErrorString(e));
-  return C4_OK;
+  return launch_common<BM, BN>(c4_head_gemm_kernel<BM, BN, WM, WN, NSTAGE, MINW>, p, 64 * WM * WN, NSTAGE * (BM + BN) * BK * 2, stream, device);
 }
 
 }  // namespace
+
+#ifdef C4_PHASE_STAMPS
+// diagnostic build only: mean shader clock (GHz) and main-loop duration (us) of the c4_head_gemm_kernel workgroups since the last reset
+extern "C" int c4_debug_gemm_clock(double* ghz, double* loop_us, uint64_t* n_workgroups, int reset) {
+  unsigned long long h[16];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(c4_gemm_clk), sizeof h) != hipSuccess) return C4_ERR_HIP;
+  if (ghz) *ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+  if (loop_us) *loop_us = h[2] ? (double)h[1] / (double)h[2] * 0.01 : 0.0;
+  if (n_workgroups) *n_workgroups = h[2];
+  if (reset) { unsigned long long z[16] = {0}; z[12] = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(c4_gemm_clk), z, sizeof z) != hipSuccess) return C4_ERR_HIP; }
+  return C4_OK;
+}
+// mean time per phase (us, 7 phases between the 8 stamps) of the workgroups since the last reset, and the span from the earliest
+// workgroup's entry to the latest one's exit (us; meaningful for ONE launch)
+extern "C" int c4_debug_gemm_phases(double* phase_us, double* span_us, int reset) {
+  unsigned long long h[16];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(c4_gemm_clk), sizeof h) != hipSuccess) return C4_ERR_HIP;
+  for (int i = 0; i < 7; i++) phase_us[i] = h[2] ? (double)h[4 + i] / (double)h[2] * 0.01 : 0.0;
+  if (span_us) *span_us = h[13] > h[12] ? (double)(h[13] - h[12]) * 0.01 : 0.0;
+  if (reset) { unsigned long long z[16] = {0}; z[12] = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(c4_gemm_clk), z, sizeof z) != hipSuccess) return C4_ERR_HIP; }
+  return C4_OK;
+}
+#endif
 
 extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float* bias_dev, void* y_dev, uint32_t m, uint32_t n,
                               uint32_t k, uint32_t ldx, uint32_t ldy, uint32_t relu, uint32_t config, void* stream) {
   if (!x_dev || !w_dev || !bias_dev || !y_dev) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: null argument");
   if (k == 0 || k % BK) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: K must be a positive multiple of 64");
   if (n == 0 || n % 192) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: N must be a positive multiple of 192 (42 x C features, C a multiple of 32)");
-  if (ldx < k || ldy < n || ldx % 8 || ldy % 4) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: row strides must cover a row and keep 16-byte (x) / 8-byte (y) alignment");
-  if ((uint64_t)m * ldx * 2 >= (1ull << 32) || (uint64_t)n * k * 2 >= (1ull << 32)) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: operands are addressed with 32-bit byte offsets (< 4 GiB each)");
+  if (ldx < k || ldy < n || ldx % 8 || ldy % 8 || ((uintptr_t)y_dev & 15) || ((uintptr_t)x_dev & 15))
+    return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: row strides must cover a row and keep rows 16-byte aligned (x and y)");
+  if ((uint64_t)m * ldx * 2 >= (1ull << 31) || (uint64_t)n * k * 2 >= (1ull << 31)) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: operands are addressed with 31-bit byte offsets (< 2 GiB each)");
   if (m == 0) return C4_OK;
   const int device = c4host::stream_device((hipStream_t)stream);
   c4host::DeviceGuard guard(device);
   if (guard.error() != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16: hipSetDevice: ") + hipGetErrorString(guard.error()));
-  GemmParams p{(const uint16_t*)x_dev, (const uint16_t*)w_dev, bias_dev, (uint16_t*)y_dev, m, n, k, ldx, ldy, relu, 0, 0, 0, 0};
+  GemmParams p{(const uint16_t*)x_dev, (const uint16_t*)w_dev, bias_dev, (uint16_t*)y_dev, m, n, k, ldx, ldy, relu, 0, 0, 0, 0, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   // Automatic choice, measured on MI355X IN THE BENCH (two sessions' kernels sharing the chip), not alone
   // (profiles/r03_gemm_configs.txt; every configuration gives the same bits): the 128 x 192 tile with
@@ -490,6 +572,12 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     case 26: return launch_gemm<192, 96, 2, 2, 2, 1>(p, st, device);   // 4 wavefronts (96 x 48), 2-deep ring, 72 KB
     case 27: return launch_gemm<64, 64, 2, 2, 4, 2>(p, st, device);    // 4 wavefronts (32 x 32), 4-deep ring, 64 KB
     case 28: return launch_gemm<96, 64, 2, 2, 3, 1>(p, st, device);    // 4 wavefronts (48 x 32), 60 KB
+    case 29: return launch_gemm<192, 192, 2, 4, 3, 1>(p, st, device);  // 8 wavefronts (96 x 48), 3-deep ring, 144 KB: 20 % fewer operand bytes per flop than 128 x 192
+    case 30: return launch_gemm<192, 192, 4, 2, 3, 1>(p, st, device);  // 8 wavefronts (48 x 96)
+    case 31: return launch_gemm32<256, 192, 4, 2, 5>(p, st, device);   // 8 wavefronts (64 x 96), 32-deep k-tiles, 5-deep ring, 140 KB
+    case 32: return launch_gemm32<256, 192, 2, 4, 5>(p, st, device);   // 8 wavefronts (128 x 48), 5-deep ring
+    case 33: return launch_gemm<192, 96, 2, 2, 4, 1>(p, st, device);   // 4 wavefronts (96 x 48), 4-deep ring, 144 KB
+    case 34: return launch_gemm<192, 192, 2, 2, 3, 1>(p, st, device);  // 4 wavefronts (96 x 96), 3-deep ring, 144 KB
     default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
   }
 }
