@@ -152,13 +152,17 @@ def whole_job(args, device, real_stdout):
         return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
 
     out, ref = {}, None
-    for name, kw in (("device_mode", dict(evaluator=net)), ("device_callback_wrapper", dict(py_eval_pos_cb=c4a0_amd.DeviceCallback(net, device))),
-                     ("numpy_callback", dict(py_eval_pos_cb=cb)),
-                     # EXTENSION rows (not the reference's algorithm, off by default): the evaluation cache answers a leaf
-                     # whose position the evaluator has already seen without an evaluator row -- same samples, because
-                     # the evaluator is a function of the position alone -- fewer lock-step rounds
-                     ("extension_eval_cache_device_mode", dict(evaluator=net, eval_cache_entries=1 << 24)),
-                     ("extension_eval_cache_numpy_callback", dict(py_eval_pos_cb=cb, eval_cache_entries=1 << 24))):
+    modes = (("device_mode", dict(evaluator=net)), ("device_callback_wrapper", dict(py_eval_pos_cb=c4a0_amd.DeviceCallback(net, device))),
+             ("numpy_callback", dict(py_eval_pos_cb=cb)),
+             # EXTENSION rows (not the reference's algorithm, off by default): the evaluation cache answers a leaf
+             # whose position the evaluator has already seen without an evaluator row -- same samples, because
+             # the evaluator is a function of the position alone -- fewer lock-step rounds
+             ("extension_eval_cache_device_mode", dict(evaluator=net, eval_cache_entries=1 << 24)),
+             ("extension_eval_cache_numpy_callback", dict(py_eval_pos_cb=cb, eval_cache_entries=1 << 24)))
+    wanted = [m for m in args.whole_job_modes.split(",") if m]
+    for name, kw in modes:
+        if wanted and name not in wanted:
+            continue
         st = {}
         # untimed: a 64-game job the same way first, so that no mode's figure carries the process's one-time costs
         # (code-object loading, the LDS opt-in, allocator warm-up) -- a training loop calls play_games every generation
@@ -178,6 +182,47 @@ def whole_job(args, device, real_stdout):
             "config": {"workload": f"src/c4a0/main.py:40-51 defaults: {n_games} games, n_mcts_iterations={n_iter}, max_nn_batch_size=2000, 1-block/32-ch ResNet (4 policy / 2 value layers) bf16"},
             **out}
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
+
+def other_config_legs(args, sessions) -> dict:
+    """The other single-GPU shapes under the driver's clock: after the headline has been measured (and
+    is already in `out`), short legs in FRESH child processes, each under a time limit so that none can cost the
+    headline -- the cpu_baseline pattern, never a re-exec.  Same code path as the headline (this file, other
+    arguments); the whole-job leg is `--whole-job` restricted to the two modes a caller of the reference uses."""
+    import subprocess
+
+    for sp in sessions:          # the children want the HBM (config 5's trees: 2 x 4 096 slots x 8 608 blocks x 128 B = 9 GB)
+        sp.close()
+    torch.cuda.empty_cache()
+    base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs"]
+    legs = {
+        "config4": base + ["--blocks", "8", "--channels", "64", "--n-mcts", "800", "--games-per-gpu", "4096", "--steps", "3", "--warmup", "1"],
+        "config5_per_gpu": base + ["--blocks", "8", "--channels", "64", "--n-mcts", "200", "--games-per-gpu", "8192", "--steps", "3", "--warmup", "1"],
+        "config5_per_gpu_dirichlet": base + ["--blocks", "8", "--channels", "64", "--n-mcts", "200", "--games-per-gpu", "8192", "--steps", "3", "--warmup", "1",
+                                             "--dirichlet", "1.0,0.25"],
+        "reference_default_job": base + ["--whole-job", "--whole-job-modes", "device_mode,numpy_callback"],
+    }
+    res = {}
+    for name, cmd in legs.items():
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.other_configs_seconds, cwd=ROOT)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                raise RuntimeError(f"child exited with {r.returncode}: {r.stderr[-300:]}")
+            d = json.loads(line[-1])
+            if name == "reference_default_job":
+                res[name] = {"workload": d["config"]["workload"],
+                             "device": {k: d["device_mode"][k] for k in ("games_per_s", "sims_per_s", "seconds", "steps", "samples")},
+                             "numpy_callback": {k: d["numpy_callback"][k] for k in ("games_per_s", "sims_per_s", "seconds", "steps", "samples", "samples_identical_to_device_mode")}}
+            else:
+                res[name] = {"workload": d["config"]["workload"], "games_per_s": d["value"], "sims_per_s": d["sims_per_s"], "ms_per_round": d["ms_per_round"],
+                             "games_completed": d["games_completed"], "timed_rounds": d["steps"] * d["config"]["rounds_per_step"],
+                             "nn_tflops": d["nn"]["achieved"], "step_kernel_us": d["roofline"]["device_clock"]["avg_kernel_us"]}
+            res[name]["leg_seconds"] = time.perf_counter() - t0
+        except Exception as e:   # a leg never costs the headline
+            res[name] = {"error": repr(e)[:400], "leg_seconds": time.perf_counter() - t0}
+    return res
 
 
 def launch_ranks(n: int, real_stdout: int) -> int:
@@ -267,6 +312,7 @@ def main():
                     help="EXTENSION, off by default and NOT part of the headline: evaluation-cache entries per session "
                          "(c4_session_set_eval_cache); repeated positions then skip the evaluator")
     ap.add_argument("--eval-cache-sims", type=int, default=0, help="simulations per game per launch with the cache (0 = 6)")
+    ap.add_argument("--dirichlet", default="", help="ALPHA,EPS: Dirichlet root noise (build extension named by BASELINE config 5; the reference has none), off by default")
     ap.add_argument("--sessions", type=int, default=2,
                     help="the resident games are split over this many sessions that replay their HIP graphs "
                          "concurrently on separate streams (1 = one session, one stream)")
@@ -282,6 +328,10 @@ def main():
                          "process under a time limit, so that the checker can never cost the GPU line)")
     ap.add_argument("--whole-job", action="store_true",
                     help="instead of the steady-state bench: the reference's default self-play job, whole, in callback and device modes (own JSON line)")
+    ap.add_argument("--whole-job-modes", default="", help="comma-separated subset of the --whole-job modes (default: all; device_mode first: the others are compared with it)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs for the other single-GPU shapes (BASELINE config 4, config 5's per-GPU share, the reference's default job) that the default N = 1 run attaches as `other_configs`")
+    ap.add_argument("--other-configs-seconds", type=float, default=150.0, help="time limit of EACH other_configs leg (a child process)")
     ap.add_argument("--whole-job-games", type=int, default=1700)
     ap.add_argument("--whole-job-n-mcts", type=int, default=1400)
     args = ap.parse_args()
@@ -340,6 +390,8 @@ def main():
         sp.set_games([(i, 0, 0) for i in ids[p::P]])
         if args.eval_cache:
             sp.set_eval_cache(args.eval_cache, args.eval_cache_sims)
+        if args.dirichlet:
+            sp.set_dirichlet(*[float(v) for v in args.dirichlet.split(",")])
         st = torch.cuda.Stream(device=device) if P > 1 else torch.cuda.current_stream(device)
         with torch.cuda.stream(st):
             sp.bind(st)
@@ -518,8 +570,12 @@ def main():
                         "not re-measured in this run")
         except Exception:
             pass
+        shape = (G, n_iter, cfg.n_residual_blocks, cfg.conv_filter_size)
+        named = {(4096, 100, 4, 32): "BASELINE config 2 per GPU", (4096, 800, 8, 64): "BASELINE config 4",
+                 (8192, 200, 8, 64): "BASELINE config 5's per-GPU share (temperature schedule on, Dirichlet noise " + (f"alpha,eps = {args.dirichlet}" if args.dirichlet else "off") + ")"
+                 }.get(shape, "custom shape (not a BASELINE configuration)")
         out = {
-            "metric": "self-play games/sec (and MCTS sims/sec) at n_mcts=100",
+            "metric": f"self-play games/sec (and MCTS sims/sec) at n_mcts={n_iter}",
             "value": games / elapsed_max,
             "unit": "games/s",
             "n_gpus": world,
@@ -532,14 +588,14 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2 per GPU: {G} concurrent games, n_mcts_iterations={n_iter}, "
+            "config": {"workload": f"{named}: {G} concurrent games, n_mcts_iterations={n_iter}, "
                                    f"{cfg.n_residual_blocks}-block/{cfg.conv_filter_size}-ch ResNet bf16, c_exploration=6.6, c_ply_penalty=0.01",
                        "rounds_per_step": R, "step": f"{R} lock-step rounds (one MCTS simulation per resident game each)",
                        "games_per_gpu": G, "n_mcts_iterations": n_iter, "parallelism": f"games sharded id%{world}",
                        "evaluator": "eager" if args.eager else (f"one hip-graph x{U} rounds of both sessions, explicitly pipelined (session.capture_pair)" if paired
                                                                 else f"hip-graph x{U} steps (evaluator + step kernel)"),
                        "concurrent_sessions": P, "games_per_session": [sp.n_slots for sp in sessions], "preroll_steps": preroll,
-                       "eval_cache_entries_per_session": args.eval_cache,
+                       "eval_cache_entries_per_session": args.eval_cache, "dirichlet_alpha_eps": args.dirichlet or None,
                        "tree_dtype": "u64 bitboards + f32 UCT"},
             "sims_per_s": sims / elapsed_max,
             "ref_equivalent_sims_per_s": (sims + skipped) / elapsed_max,
@@ -591,6 +647,9 @@ def main():
                 out["cpu_baseline"] = json.loads(line[-1])
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+        if world == 1 and not args.no_other_configs and shape == (4096, 100, 4, 32):
+            out["other_configs"] = other_config_legs(args, sessions)
+            sessions = []
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     for sp in sessions:
         sp.close()
