@@ -23,7 +23,10 @@ SRCS = [os.path.join(HERE, "c4_session.hip"), os.path.join(HERE, "c4_conv_tower.
 DEPS = SRCS + [os.path.join(HERE, "c4_device.hpp"), os.path.join(HERE, "c4_host.hpp"),
                os.path.join(os.path.dirname(PKG), "include", "c4a0_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         # scalar kernel arguments (up to 16 dwords) arrive in SGPRs at wavefront launch instead of by a scalar load from
+         # the kernarg segment: the hot kernels take their pointers and sizes as leading scalar arguments for this
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 MARKER = b"c4a0-src-hash:"
 
 

@@ -357,7 +357,10 @@ __device__ __forceinline__ void dma_weights(const void* w, uint32_t bytes, uint4
 
 // ST (C = 64): the residual layers run as tower_layer_stream (weights streamed through a ring, k-steps outside).
 template <int C, int NB, int NT, int MS, bool ST = false>
-__global__ __launch_bounds__(NT) void c4_conv_tower_kernel(TowerParams p) {
+__global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __restrict__ a_planes, const bf16x8* __restrict__ a_w0, const bf16x8* __restrict__ a_w,
+                                                             const float* __restrict__ a_bias, uint16_t* __restrict__ a_out, uint32_t a_n_boards, uint32_t a_n_blocks) {
+  // flat scalar arguments (12 dwords): preloaded into SGPRs at wavefront launch (build.py: -amdgpu-kernarg-preload-count)
+  const TowerParams p{a_planes, a_w0, a_w, a_bias, a_out, a_n_boards, a_n_blocks};
   using G = Geo<C, NB>;
   constexpr int MTW = G::MT / MS;
   static_assert(G::MT % MS == 0 && (!G::kStageW || MS == 1), "co-tile split");
@@ -522,7 +525,7 @@ int launch_tower(const TowerParams& p, uint32_t n_boards, hipStream_t stream, in
   auto k = c4_conv_tower_kernel<C, NB, NT, MS, ST>;
   hipError_t e = c4host::opt_in_lds((const void*)k, kLds, device);
   if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: LDS opt-in (") + std::to_string(kLds) + " bytes) on device " + std::to_string(device) + ": " + hipGetErrorString(e));
-  k<<<dim3((n_boards + NB - 1) / NB), dim3(NT), kLds, stream>>>(p);
+  k<<<dim3((n_boards + NB - 1) / NB), dim3(NT), kLds, stream>>>(p.planes, p.w0, p.w, p.bias, p.out, p.n_boards, p.n_blocks);
   e = hipGetLastError();
   if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16 launch: ") + hipGetErrorString(e));
   return C4_OK;

@@ -52,6 +52,18 @@ struct GemmParams {
   uint32_t xcd_mask, xcd_shift, xn_log2, rm, rn, rn_magic;
 };
 
+// Kernel arguments are FLAT scalars (14 dwords), not a struct: with -mllvm -amdgpu-kernarg-preload-count=16 (build.py)
+// the command processor hands them to the wavefront in SGPRs at launch, and the kernel no longer opens with two
+// dependent scalar-load round trips to the kernarg segment (0.84 us from entry to the last prologue DMA issue with
+// the struct, measured with the diagnostic build's stamps).
+#define C4_GEMM_ARGS const uint16_t* __restrict__ a_x, const uint16_t* __restrict__ a_w, const float* __restrict__ a_bias, uint16_t* __restrict__ a_y, \
+                     uint32_t a_m, uint32_t a_nk, uint32_t a_ld, uint32_t a_flags, uint32_t a_rmrn, uint32_t a_magic
+#define C4_GEMM_UNPACK()                                                                                                              \
+  GemmParams p;                                                                                                                        \
+  p.x = a_x; p.w = a_w; p.bias = a_bias; p.y = a_y; p.M = a_m; p.N = a_nk & 0xFFFFu; p.K = a_nk >> 16; p.ldx = a_ld & 0xFFFFu;         \
+  p.ldy = a_ld >> 16; p.relu = a_flags & 0xFFu; p.xn_log2 = (a_flags >> 8) & 0xFFu; p.xcd_mask = (a_flags >> 16) & 0xFFu;              \
+  p.xcd_shift = a_flags >> 24; p.rm = a_rmrn & 0xFFFFu; p.rn = a_rmrn >> 16; p.rn_magic = a_magic
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -138,7 +150,8 @@ __device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[TN][TM], cons
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(C4_GEMM_ARGS) {
+  C4_GEMM_UNPACK();
   constexpr int kWaves = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;        // 16 x 16 output tiles per wavefront
   constexpr int kStageBytes = (BM + BN) * BK * 2;
@@ -324,7 +337,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(GemmPa
 // Every output element still sees the same chain (k ascending, 32 at a time): same bits as above.
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(64 * WM * WN, 1) void c4_head_gemm32_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, 1) void c4_head_gemm32_kernel(C4_GEMM_ARGS) {
+  C4_GEMM_UNPACK();
   constexpr int BKT = 32;
   constexpr int kWaves = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -465,7 +479,8 @@ int launch_common(K k, GemmParams p, int threads, int lds_bytes, hipStream_t str
     if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16: LDS opt-in: ") + hipGetErrorString(e));
   }
   const uint32_t tiles = set_tile_order(p, (p.M + BM - 1) / BM, p.N / BN, BM, BN);
-  k<<<dim3(tiles), dim3(threads), lds_bytes, stream>>>(p);
+  k<<<dim3(tiles), dim3(threads), lds_bytes, stream>>>(p.x, p.w, p.bias, p.y, p.M, p.N | (p.K << 16), p.ldx | (p.ldy << 16),
+                                                         (p.relu ? 1u : 0u) | (p.xn_log2 << 8) | (p.xcd_mask << 16) | (p.xcd_shift << 24), p.rm | (p.rn << 16), p.rn_magic);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16 launch: ") + hipGetErrorString(e));
   return C4_OK;
@@ -514,6 +529,7 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
   if (ldx < k || ldy < n || ldx % 8 || ldy % 8 || ((uintptr_t)y_dev & 15) || ((uintptr_t)x_dev & 15))
     return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: row strides must cover a row and keep rows 16-byte aligned (x and y)");
   if ((uint64_t)m * ldx * 2 >= (1ull << 31) || (uint64_t)n * k * 2 >= (1ull << 31)) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: operands are addressed with 31-bit byte offsets (< 2 GiB each)");
+  if (n >= 65536 || k >= 65536 || ldx >= 65536 || ldy >= 65536) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: n, k and the row strides must be below 65 536 (packed kernel arguments)");
   if (m == 0) return C4_OK;
   const int device = c4host::stream_device((hipStream_t)stream);
   c4host::DeviceGuard guard(device);

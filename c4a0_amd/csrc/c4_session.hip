@@ -482,7 +482,12 @@ C4_DEV void timing_helper(const Params& p, uint32_t lane) {
 #define C4_STEP_WAVES 4
 #endif
 template <typename PlaneT, bool NOISE, bool CACHE>
-__global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_step_kernel(Params p) {
+__global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_step_kernel(
+    // What the head of every wavefront's dependent chain needs, as leading SCALAR arguments (copies of p's fields): with
+    // -mllvm -amdgpu-kernarg-preload-count (build.py) they are in SGPRs when the wavefront starts, so the state line and
+    // the evaluator's outputs are requested at once instead of behind a scalar-load round trip to the kernarg segment.
+    Slot* __restrict__ a_slots, const float* __restrict__ a_logprobs, const float* __restrict__ a_q, uint32_t a_n_waves, uint32_t a_n_slots,
+    Params p) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t sub = lane & 7;
   const int gbase = (int)(lane & ~7u);
@@ -495,22 +500,22 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
 #ifdef C4_PHASE_STAMPS
   if (lane == 0) for (int i = 9; i < 16; i++) p.phase[(size_t)blockIdx.x * 16 + i] = 0;
 #endif
-  if (blockIdx.x >= p.n_waves) { timing_helper(p, lane); return; }
+  if (blockIdx.x >= a_n_waves) { timing_helper(p, lane); return; }
 
-  const uint32_t gs = g < p.n_slots ? g : 0;
-  Slot* st = p.slots + gs;
+  const uint32_t gs = g < a_n_slots ? g : 0;
+  Slot* st = a_slots + gs;
   // The game's state: ONE 128-byte line, 16 bytes per lane in one instruction; the evaluator's
   // outputs for this game travel in the same round trip.
   const uint4 hot = reinterpret_cast<const uint4*>(st)[sub];
-  const float nn_logit = p.logprobs[(size_t)gs * 7 + (sub < 7 ? sub : 6)];
-  const float nn_q = p.q[(size_t)gs * 2 + (sub & 1)];
+  const float nn_logit = a_logprobs[(size_t)gs * 7 + (sub < 7 ? sub : 6)];
+  const float nn_q = a_q[(size_t)gs * 2 + (sub & 1)];
   // ... and they must LEAVE together: without this fence hipcc sinks the two evaluator loads into the
   // `if (active)` below, i.e. behind the wait for the state line -- a second, serial memory round trip (plus the
   // scalar loads of the two pointers) at the head of every wavefront's chain (round 3, found in the ISA).
   __builtin_amdgcn_sched_barrier(0);
   // header words to every lane of the group (lane 3: state, arena, root ref, rng word)
   const uint32_t state0 = shfl_u32(hot.x, gbase + 3);
-  bool active = (g < p.n_slots) && (slot_status(state0) == kActive);
+  bool active = (g < a_n_slots) && (slot_status(state0) == kActive);
   uint4 line = hot;          // what goes back to the slot at the end
   bool store_line = false;
   // move RNG precompute (see the end of the kernel): what this game will need at its next move
@@ -1533,7 +1538,9 @@ int c4_session_step(c4_session* s) {
 #endif
   // a timed launch (seq != 0) carries extra workgroups that fold the previous launch's stamps
   const uint32_t helpers = s->p.seq ? (s->n_waves + kWavesPerTimingHelper - 1) / kWavesPerTimingHelper : 0u;
-  auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(s->n_waves + helpers), dim3(64), lds_pad, s->stream, s->p); };
+  auto launch = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(s->n_waves + helpers), dim3(64), lds_pad, s->stream, s->p.slots, s->p.logprobs, s->p.q, s->p.n_waves, s->p.n_slots, s->p);
+  };
   const bool f32 = s->cfg.planes_dtype == 0;
 #define C4_LAUNCH_STEP(KERNEL)                                                                                       \
   do {                                                                                                               \
