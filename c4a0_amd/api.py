@@ -246,7 +246,9 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
         raise TypeError("eval_cache_entries needs ONE evaluator (not evaluator={model_id: ...})")
     # longer graphs amortise the replay boundary (+2.5 % at 32); all but very long jobs keep the finer
     # stop granularity (a 16 384-game job: 16.0 k games/s at 8 steps per graph, 14.9 k at 32)
-    steps_per_graph = (32 if len(reqs) >= 32 * n_slots else 8) if graph_safe else 0
+    # ... and jobs of few but long games (the reference's default job: 1 700 games, n = 1 400: 37 000 rounds) replay 32 rounds
+    # per graph too: the stop granularity is then 0.1 % of the job and the replay boundary 1.5 us per round at 8
+    steps_per_graph = (32 if (len(reqs) >= 32 * n_slots or int(n_mcts_iterations) >= 400) else 8) if graph_safe else 0
     if hasattr(evaluator, "latency_mode"):   # InferenceNet: tile choice of the narrow layers, alone vs beside another session
         evaluator.latency_mode = parts == 1
     sessions = []

@@ -249,7 +249,11 @@ class InferenceNet:
             hook(0)
         x = self.tower(planes)
         if self.merged_w1 is not None:
-            # first hidden layer of BOTH heads as one GEMM (same input, N = 2F): better tile occupancy
+            # first hidden layer of BOTH heads as one GEMM (same input, N = 2F): better tile occupancy.  (Round 4 tried the two
+            # halves as two launches, the value head's on a side stream beside the policy head's second layer, so that a
+            # session's chain holds an F-wide layer instead of the 2F-wide one: same bits, but every cross-stream edge
+            # costs more than the 3.5 us it saves -- the bench halved, 28.0 -> 13.7 k games/s -- and ROCm 7.2's
+            # hipStreamEndCapture crashes on a fork from a non-origin stream, tools/capture_nested_fork_repro.py.)
             h = self._linear_relu(x, self.merged_w1, self.merged_b1)
             if hook is not None:
                 hook(1)
@@ -304,7 +308,7 @@ class InferenceNet:
             return 23
         return 0 if n > k else 10
 
-    def _linear_relu(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    def _linear_relu(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ReLU(x W^T + b): the hand-written MFMA GEMM, or (gemm="hipblaslt") the library's with the bias
         and ReLU in its epilogue where available."""
         if self.gemm == "hip":
@@ -313,9 +317,9 @@ class InferenceNet:
 
             assert x.stride(1) == 1 and w.is_contiguous()
             m, n, k = x.shape[0], w.shape[0], w.shape[1]
-            y = torch.empty((m, n), dtype=torch.bfloat16, device=self.device)
+            y = out if out is not None else torch.empty((m, n), dtype=torch.bfloat16, device=self.device)
             check(self._L.c4_linear_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(self._bias32[b.data_ptr()].data_ptr()),
-                                         C.c_void_p(y.data_ptr()), m, n, k, x.stride(0), n, 1,
+                                         C.c_void_p(y.data_ptr()), m, n, k, x.stride(0), y.stride(0), 1,
                                          self.gemm_config[0 if n > k else 1] or self._alone_config(m, n, k),
                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             return y
