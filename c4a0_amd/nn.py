@@ -306,7 +306,7 @@ class InferenceNet:
             return 0 if n > k else 11   # (alone at 2 048 rows: 31 us against 49)
         if m <= 1728:
             return 23
-        return 0 if n > k else 10
+        return 11 if n > k else 10   # (alone the 8-wavefront form of the 128 x 192 tile is the faster one for the 2F-wide layer)
 
     def _linear_relu(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ReLU(x W^T + b): the hand-written MFMA GEMM, or (gemm="hipblaslt") the library's with the bias
