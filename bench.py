@@ -51,6 +51,16 @@ def algorithmic_bytes(c: dict, planes_bytes_per_elem: int) -> dict:
     return {"select_backup": sb, "expand": ex, "encode": enc, "total": sb + ex + enc}
 
 
+def step_kernel_source_hash() -> str:
+    """sha256 over the two files the step kernel is compiled from (profiles/step_kernel_traffic.json records it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("c4_session.hip", "c4_device.hpp"):
+        with open(os.path.join(ROOT, "c4a0_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def usable_cores() -> int:
     try:
         n = len(os.sched_getaffinity(0))
@@ -322,6 +332,7 @@ def main():
     ap.add_argument("--gemm", default=None, choices=["hip", "hipblaslt"],
                     help="A/B knob: hidden-layer GEMM backend (default: the hand-written batch-invariant MFMA GEMM)")
     ap.add_argument("--gemm-config", default=None, help="A/B knob: c4_linear_bf16 tile configuration, N or 'wide,narrow' (0 = automatic)")
+    ap.add_argument("--pair-offset", type=int, default=1, help="A/B knob: capture_pair's offset_stage (session B starts when this stage of A's first round is done)")
     ap.add_argument("--tower-config", type=int, default=0, help="A/B knob: c4_conv_tower_bf16 workgroup shape (0 = automatic)")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="internal: compute the cpu_baseline object alone and print it (the bench runs this leg in a child "
@@ -409,8 +420,8 @@ def main():
     pair_graph = pair_graph1 = None
     if paired:   # both sessions' rounds in ONE graph, explicitly pipelined against each other (session.capture_pair)
         from c4a0_amd.session import capture_pair
-        pair_graph = capture_pair(sessions, streams, net, U)
-        pair_graph1 = capture_pair(sessions, streams, net, 1) if U > 1 else pair_graph
+        pair_graph = capture_pair(sessions, streams, net, U, offset_stage=args.pair_offset)
+        pair_graph1 = capture_pair(sessions, streams, net, 1, offset_stage=args.pair_offset) if U > 1 else pair_graph
 
     # RCCL comes up only now, AFTER the HIP graphs are captured: its watchdog thread must not poll
     # events while a stream capture is open
@@ -553,19 +564,24 @@ def main():
         # s_memrealtime stamps taken inside the kernel): what rocprofv3's kernel duration measures
         dev_s = di["step_kernel_ns"] / 1e9 / max(1, di["step_launches"])
         achieved_dev = ab["total"] / n_inst / max(dev_s, 1e-12) / 1e9
-        traffic = None
+        traffic, traffic_current = None, None
         tpath = os.path.join(ROOT, "profiles", "step_kernel_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                # counters are collected in their own rocprofv3 --pmc passes (tools/profile/run_r04.sh), not in this run: say whether
+                # they were taken on the step kernel this library holds (hash of c4_session.hip + c4_device.hpp at collection time)
+                traffic_current = tj.get("step_kernel_source_hash") == step_kernel_source_hash()
             except Exception:
                 traffic = None
         fl = flops_per_leaf(cfg)
         mfma_busy, mfma_src = None, None   # counters under the evaluator: not re-measured here, read from the committed PMC summary
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_evaluator_pmc.json")))
+            pmc_file = next(f for f in ("r04_evaluator_pmc.json", "r03_evaluator_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             mfma_busy = pm["backends"]["hip0" if net.gemm == "hip" else "hipblaslt0"]["evaluator_mfma_busy_frac_of_chip_time_weighted"]
-            mfma_src = ("profiles/r03_evaluator_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles), time-weighted over the tower, the three "
+            mfma_src = (f"profiles/{pmc_file}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles), time-weighted over the tower, the three "
                         "hidden-layer GEMMs and the output kernel, each launch ALONE on the chip at 2 048 rows (rocprofv3 --pmc serialises kernels); "
                         "not re-measured in this run")
         except Exception:
@@ -609,6 +625,11 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic,
                          "traffic_source": "profiles/step_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, corrected per MI355X_MICROARCH.md); not re-measured in this run",
+                         "traffic_collected_on_this_step_kernel": traffic_current,
+                         # the memory system's ceiling for THIS access pattern (random whole 128-byte lines from an HBM-resident table,
+                         # tools/gather_lab.hip): 6.7 TB/s, i.e. 84 % of the 8 TB/s the fraction above is quoted against
+                         "frac_of_practical_ceiling": achieved / 6700.0,
+                         "device_clock_frac_of_practical_ceiling": achieved_dev / 6700.0,
                          "avg_launch_us": avg_kernel_s * 1e6,
                          "device_clock": {"avg_kernel_us": dev_s * 1e6, "achieved": achieved_dev, "frac": achieved_dev / HBM_PEAK_GBPS,
                                           "note": "in-kernel s_memrealtime stamps; the HIP-event bracket adds the dispatch and completion latency of one launch"},

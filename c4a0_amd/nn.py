@@ -126,8 +126,9 @@ class InferenceNet:
                           # second session's kernels the fat 128 x 192 tile wins, c4_head_gemm.hip) and the 32-channel
                           # tower 8 boards per workgroup up to 2 048 boards (27.3 -> 19.1 us alone at 2 048)
     graph_safe = True  # forward() is pure device work on caller-owned outputs: may be captured in a HIP graph
-    stage_hook = None  # optional callable(stage): 0 = before the tower is launched, 1 = after the first hidden layer's
-                       # GEMM is launched (session.capture_pair records / waits cross-stream events there)
+    stage_hook = None  # optional callable(stage): 0 = before the tower is launched, 2 = after it, 1 = after the first hidden layer's
+                       # GEMM is launched, 3 + i = after the policy head's i-th further layer (session.capture_pair records /
+                       # waits cross-stream events there)
 
     def __init__(self, model: ConnectFourNet, device: torch.device, dtype: torch.dtype = torch.bfloat16,
                  hip_tower: Optional[bool] = None, gemm: Optional[str] = None, gemm_config=None, tower_config: int = 0):
@@ -248,6 +249,8 @@ class InferenceNet:
         if hook is not None:
             hook(0)
         x = self.tower(planes)
+        if hook is not None:
+            hook(2)                # after the tower is launched (capture_pair's offset_stage measurements)
         if self.merged_w1 is not None:
             # first hidden layer of BOTH heads as one GEMM (same input, N = 2F): better tile occupancy.  (Round 4 tried the two
             # halves as two launches, the value head's on a side stream beside the policy head's second layer, so that a

@@ -7,6 +7,14 @@ import os
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def step_hash():
+    sys.path.insert(0, root)
+    import bench
+    return bench.step_kernel_source_hash()
+
+
 path = os.path.join(root, "profiles", "step_kernel_traffic.json")
 old = json.load(open(path))
 f, w = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
@@ -21,7 +29,7 @@ new = dict(old)
 new.update({"launches_averaged": int(min(f["dispatches_averaged"], w["dispatches_averaged"])), "FETCH_SIZE_KB_per_launch": round(fk, 1),
             "WRITE_SIZE_KB_per_launch": round(wk, 1), "hbm_bytes_per_launch_raw": int(raw), "hbm_bytes_per_launch": int(corr),
             "algorithmic_bytes_per_launch": int(alg), "ratio_raw": round(raw / alg, 2), "ratio_fetch_doubled": round(corr / alg, 2),
-            "history": hist, "note": label,
-            "command": old["command"].replace("tools/profile/run_r02.sh", "tools/profile/run_r03.sh")})
+            "history": hist, "note": label, "step_kernel_source_hash": step_hash(),
+            "command": old["command"].replace("tools/profile/run_r02.sh", "tools/profile/run_r04.sh").replace("tools/profile/run_r03.sh", "tools/profile/run_r04.sh")})
 json.dump(new, open(path, "w"), indent=1)
 print(json.dumps({k: new[k] for k in ("FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "ratio_raw", "ratio_fetch_doubled")}))
