@@ -678,7 +678,7 @@ __global__ __launch_bounds__(64 * kHeadWaves, 1) void c4_head_out_mfma_kernel(
   const uint4* wpl = wp + (size_t)(row < 7 ? row : 0) * f8 + kq;           // B column = output `row`
   const uint4* wvl = wv + (size_t)(row < 2 ? row : 0) * f8 + kq;
   f32x4 accp = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
-#ifdef C4_PHASE_STAMPS   // diagnostic build: where does a workgroup of this kernel spend its time?
+#ifdef C4_HEAD_OUT_TRACE   // (-DC4_HEAD_OUT_TRACE on top of the diagnostic build) where does a workgroup of this kernel spend its time?
   unsigned long long hs[6];
 #define C4_HSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); hs[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(64 * kHeadWaves, 1) void c4_head_out_mfma_kernel(
       q[(size_t)gb * 2 + 1] = tanhf(v[8]);
     }
   }
-#ifdef C4_PHASE_STAMPS
+#ifdef C4_HEAD_OUT_TRACE
   C4_HSTAMP(5);
   if (threadIdx.x == 0 && (blockIdx.x == 3 || blockIdx.x == 77))
     printf("head_out wg %u: loads %llu  mfma %llu  partials+barrier %llu  sum+barrier %llu  softmax/tanh+stores %llu  (10 ns ticks)\n", blockIdx.x,

@@ -67,8 +67,11 @@ struct GemmParams {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-#ifdef C4_PHASE_STAMPS
-// Diagnostic build only (tools/clock_probe.py): (a) the shader clock a GEMM's main loop actually ran at -- shader cycles
+#if defined(C4_PHASE_STAMPS) && !defined(C4_GEMM_CLOCK)
+#define C4_GEMM_CLOCK   // the diagnostic build carries the GEMM clock stamps; -DC4_GEMM_CLOCK alone = the product kernels + these stamps
+#endif
+#ifdef C4_GEMM_CLOCK
+// Diagnostic builds only (tools/clock_probe.py, tools/bench_clock.py): (a) the shader clock a GEMM's main loop actually ran at -- shader cycles
 // (s_memtime) over constant 100 MHz ticks (s_memrealtime) -- and (b) where a workgroup's time goes: stamps 0 entry,
 // 1 prologue issued, 2 first k-tile landed (first barrier passed), 3 main loop done, 4 tail DMA drained, 5 bias arrived,
 // 6 stores issued, 7 stores acknowledged; summed over the first wavefront of every workgroup, plus the earliest entry
@@ -78,17 +81,29 @@ __device__ unsigned long long c4_gemm_clk[16];   // {cycles, ticks, workgroups, 
 #define C4_GSTAMP(i) do { clk_ts[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define C4_CLK_BEGIN() do { clk_c0 = __builtin_amdgcn_s_memtime(); } while (0)
 #define C4_CLK_END() do { clk_c1 = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef C4_PHASE_STAMPS
+#define C4_CLK_SAMPLE() true                       /* the diagnostic build: every workgroup, every phase */
+#else
+#define C4_CLK_SAMPLE() ((blockIdx.x & 31) == 5)   /* -DC4_GEMM_CLOCK alone (tools/bench_clock.py): one workgroup in 32, so that the atomics do not slow the run being measured */
+#endif
 #define C4_CLK_FLUSH()                                                                                       \
   do {                                                                                                       \
-    if (threadIdx.x == 0) {                                                                                  \
+    if (threadIdx.x == 0 && C4_CLK_SAMPLE()) {                                                               \
       atomicAdd(&c4_gemm_clk[0], clk_c1 - clk_c0);                                                           \
       atomicAdd(&c4_gemm_clk[1], clk_ts[3] - clk_ts[1]);                                                     \
       atomicAdd(&c4_gemm_clk[2], 1ull);                                                                      \
-      for (int i_ = 0; i_ < 7; i_++) atomicAdd(&c4_gemm_clk[4 + i_], clk_ts[i_ + 1] - clk_ts[i_]);           \
-      atomicMin(&c4_gemm_clk[12], clk_ts[0]);                                                                \
-      atomicMax(&c4_gemm_clk[13], clk_ts[7]);                                                                \
+      if (C4_CLK_PHASES) {                                                                                   \
+        for (int i_ = 0; i_ < 7; i_++) atomicAdd(&c4_gemm_clk[4 + i_], clk_ts[i_ + 1] - clk_ts[i_]);         \
+        atomicMin(&c4_gemm_clk[12], clk_ts[0]);                                                              \
+        atomicMax(&c4_gemm_clk[13], clk_ts[7]);                                                              \
+      }                                                                                                      \
     }                                                                                                        \
   } while (0)
+#ifdef C4_PHASE_STAMPS
+#define C4_CLK_PHASES 1
+#else
+#define C4_CLK_PHASES 0
+#endif
 #else
 #define C4_CLK_DECL() do { } while (0)
 #define C4_GSTAMP(i) do { } while (0)
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(C4_GEM
     // see issue_one for the pieces past the last k-tile)
     wait_vmcnt<(NSTAGE - 2) * L>();
     __builtin_amdgcn_s_barrier();                               // everybody's pieces of kt landed; everybody left buffer (kt - 1) % NSTAGE
-#ifdef C4_PHASE_STAMPS
+#ifdef C4_GEMM_CLOCK
     if (kt == 0) C4_GSTAMP(2);
 #endif
     // The DMA pieces of k-tile kt + NSTAGE - 1 are NOT issued here in one burst (a wavefront would spend
@@ -315,8 +330,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(C4_GEM
   C4_GSTAMP(5);
   store_wave_tile<TM, TN>(acc, bias_v, p, tm0 + wm * (BM / WM), tn0 + wn * (BN / WN), li, lg);
   C4_GSTAMP(6);
-#ifdef C4_PHASE_STAMPS
-  wait_vmcnt<0>();
+#ifdef C4_GEMM_CLOCK
+  if (C4_CLK_PHASES) wait_vmcnt<0>();
   C4_GSTAMP(7);
   C4_CLK_FLUSH();
 #endif
@@ -498,8 +513,8 @@ int launch_gemm(GemmParams p, hipStream_t stream, int device) {
 
 }  // namespace
 
-#ifdef C4_PHASE_STAMPS
-// diagnostic build only: mean shader clock (GHz) and main-loop duration (us) of the c4_head_gemm_kernel workgroups since the last reset
+#ifdef C4_GEMM_CLOCK
+// diagnostic builds only: mean shader clock (GHz) and main-loop duration (us) of the c4_head_gemm_kernel workgroups since the last reset
 extern "C" int c4_debug_gemm_clock(double* ghz, double* loop_us, uint64_t* n_workgroups, int reset) {
   unsigned long long h[16];
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(c4_gemm_clk), sizeof h) != hipSuccess) return C4_ERR_HIP;

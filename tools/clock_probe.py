@@ -45,6 +45,9 @@ def linear(x, w, b32, y, cfg):
                                 m, n, k, x.stride(0), y.stride(0), 1, cfg, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
+REPS = 300
+
+
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     cfgs = [int(c) for c in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["11"])]
@@ -56,18 +59,18 @@ def main():
             w = (torch.randn(N, F, device=dev) / F ** 0.5).to(torch.bfloat16)
             b32 = torch.randn(N, device=dev)
             y = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-            for _ in range(200):     # warm: clocks settle after ~ms of load
+            for _ in range(100):     # warm: clocks settle after ~ms of load
                 linear(x, w, b32, y, cfg)
             read()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            for _ in range(2000):
+            for _ in range(REPS):
                 linear(x, w, b32, y, cfg)
             b.record()
             torch.cuda.synchronize()
             ghz, us, n = read(reset=False)
             ph, _ = phases()
-            print(f"cfg {cfg} M {M} N {N} alone: {a.elapsed_time(b) / 2000 * 1e3:.1f} us per launch; main loop {us:.2f} us at {ghz:.3f} GHz "
+            print(f"cfg {cfg} M {M} N {N} alone: {a.elapsed_time(b) / REPS * 1e3:.1f} us per launch; main loop {us:.2f} us at {ghz:.3f} GHz "
                   f"= {us * ghz * 1e3 / 21:.0f} cycles per k-tile ({n} workgroups)", flush=True)
             print("    mean workgroup, us: " + "  ".join(f"{nm} {v:.2f}" for nm, v in zip(PHASES, ph)), flush=True)
             spans = []
@@ -77,6 +80,8 @@ def main():
                 spans.append(phases()[1])
             spans.sort()
             print(f"    in-kernel span of one launch (first entry -> last exit): median {spans[10]:.2f} us, min {spans[0]:.2f}", flush=True)
+    if len(sys.argv) > 3 and sys.argv[3] == "gemm-only":
+        return
     torch.manual_seed(1337)
     net = InferenceNet(ConnectFourNet(ModelConfig(4, 32, 4, 2)), dev, dtype=torch.bfloat16)
     planes = (torch.rand(M, 2, 6, 7, device=dev) > 0.7).to(torch.bfloat16)
