@@ -332,6 +332,7 @@ def main():
     ap.add_argument("--gemm", default=None, choices=["hip", "hipblaslt"],
                     help="A/B knob: hidden-layer GEMM backend (default: the hand-written batch-invariant MFMA GEMM)")
     ap.add_argument("--gemm-config", default=None, help="A/B knob: c4_linear_bf16 tile configuration, N or 'wide,narrow' (0 = automatic)")
+    ap.add_argument("--no-fused-step", action="store_true", help="A/B knob: output kernel and step kernel as two launches (round 3) instead of one")
     ap.add_argument("--pair-offset", type=int, default=1, help="A/B knob: capture_pair's offset_stage (session B starts when this stage of A's first round is done)")
     ap.add_argument("--tower-config", type=int, default=0, help="A/B knob: c4_conv_tower_bf16 workgroup shape (0 = automatic)")
     ap.add_argument("--cpu-baseline-only", action="store_true",
@@ -375,6 +376,8 @@ def main():
     from c4a0_amd.session import DeviceSession
 
     G, n_iter = args.games_per_gpu, args.n_mcts
+    if args.no_fused_step:
+        DeviceSession.fuse_output_step = False
     cfg = ModelConfig(args.blocks, args.channels, 4, 2)
     torch.manual_seed(1337)
     net = InferenceNet(ConnectFourNet(cfg), device, dtype=torch.bfloat16, gemm=args.gemm, gemm_config=args.gemm_config,

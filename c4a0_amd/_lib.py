@@ -19,7 +19,7 @@ STATUS_NAMES = {
 FLAG_NO_MOVES = 1
 FLAG_ONE_SIM_PER_STEP = 2
 MAX_SAMPLES_PER_GAME = 43
-ABI_VERSION = 4   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
+ABI_VERSION = 5   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
 
 
 class C4Error(RuntimeError):
@@ -72,6 +72,7 @@ SIGNATURES = {
     "c4_session_compact": (C.c_int, [_vp, C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
     "c4_session_start": (C.c_int, [_vp]),
     "c4_session_step": (C.c_int, [_vp]),
+    "c4_session_step_head_out": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "c4_session_set_timing": (C.c_int, [_vp, C.c_int]),
     "c4_session_counters": (C.c_int, [_vp, _P(Counters)]),
     "c4_session_poll": (C.c_int, [_vp, _P(C.c_uint64), _P(C.c_uint32)]),

@@ -32,6 +32,7 @@
 #include <string>
 
 #include "../../include/c4a0_hip.h"
+#include "c4_head_out.hpp"
 #include "c4_host.hpp"
 
 namespace {
@@ -652,110 +653,17 @@ __global__ __launch_bounds__(256) void c4_head_out_kernel(const uint4* __restric
 }
 
 
-// MFMA form of the same computation (used when F is a multiple of 32 * 7 * 6, i.e. F = 42 * C):
-// a workgroup owns 16 boards; D[board][output] = sum_k X[board][k] * W[output][k] with
-// v_mfma_f32_16x16x32_bf16 (A = 16 boards x 32 features straight from global memory, B = the 7 or 2
-// weight rows, zero-padded to 16 columns).  The feature dimension is split over 6 wavefronts,
-// every wavefront requests all of its operands before the first MFMA (one memory round trip), and
-// the partial tiles meet in LDS.  No cross-lane reduction per output, 16-byte loads only.
-constexpr int kHeadWaves = 6, kHeadSteps = 7;
-// kRows = boards per workgroup: 16 (every row of the MFMA tile a board) or 8 (small launches: twice the workgroups, so
-// that a 2 048-board launch uses every CU and each CU pulls half the activations; rows 8..15 repeat rows 0..7).
+// MFMA form of the same computation (used when F is a multiple of 32 * 7 * 6, i.e. F = 42 * C): c4_head_out.hpp, shared with
+// the fused output + step kernel of c4_session.hip.
+using c4ho::kHeadSteps;
+using c4ho::kHeadWaves;
 template <int kRows>
 __global__ __launch_bounds__(64 * kHeadWaves, 1) void c4_head_out_mfma_kernel(
     const uint4* __restrict__ hp, const uint4* __restrict__ hv, const uint4* __restrict__ wp, const uint4* __restrict__ wv,
     const float* __restrict__ bp, const float* __restrict__ bv, uint32_t n_boards, uint32_t f8, uint32_t sp8, uint32_t sv8,
     float* __restrict__ logprobs, float* __restrict__ q) {
-  __shared__ f32x4 part[kHeadWaves][2][64];
-  __shared__ float tile[2][16][17];
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t row = lane & 15, kq = lane >> 4;
-  const uint32_t g0 = blockIdx.x * kRows;
-  const uint32_t gr = g0 + (row & (kRows - 1));
-  const uint32_t g = gr < n_boards ? gr : n_boards - 1;                   // tail rows recompute the last board (never stored)
-  const uint4* xp = hp + (size_t)g * sp8 + kq;
-  const uint4* xv = hv + (size_t)g * sv8 + kq;
-  const uint4* wpl = wp + (size_t)(row < 7 ? row : 0) * f8 + kq;           // B column = output `row`
-  const uint4* wvl = wv + (size_t)(row < 2 ? row : 0) * f8 + kq;
-  f32x4 accp = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
-#ifdef C4_HEAD_OUT_TRACE   // (-DC4_HEAD_OUT_TRACE on top of the diagnostic build) where does a workgroup of this kernel spend its time?
-  unsigned long long hs[6];
-#define C4_HSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); hs[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define C4_HSTAMP(i) do { } while (0)
-#endif
-  C4_HSTAMP(0);
-  const uint32_t n_iter = f8 / (4 * kHeadSteps * kHeadWaves);
-  for (uint32_t it = 0; it < n_iter; it++) {
-    const uint32_t s0 = (it * kHeadWaves + wave) * kHeadSteps;           // first k-step (of 32 features) of this wavefront
-    uint4 a_p[kHeadSteps], a_v[kHeadSteps], b_p[kHeadSteps], b_v[kHeadSteps];
-#pragma unroll
-    for (int s = 0; s < kHeadSteps; s++) {
-      a_p[s] = xp[4 * (s0 + s)];
-      a_v[s] = xv[4 * (s0 + s)];
-      b_p[s] = wpl[4 * (s0 + s)];      // every lane loads (lanes beyond the 7 / 2 outputs re-read row 0) and is masked AFTERWARDS:
-      b_v[s] = wvl[4 * (s0 + s)];      // a "load or zero" select makes hipcc branch around each load and drain vmcnt per element
-    }
-    // (round 3: with the select in the loop above the 28 requests of a wavefront went out two at a time, each pair
-    // waited for -- twelve serial memory round trips, 8.2 of the kernel's 8.6 us.  Now one round trip.)
-    __builtin_amdgcn_sched_barrier(0);   // ... and the scheduler must not re-interleave loads and MFMAs to save registers
-    const uint32_t mp = row < 7 ? 0xFFFFFFFFu : 0u, mv = row < 2 ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-    for (int s = 0; s < kHeadSteps; s++) {
-      b_p[s].x &= mp; b_p[s].y &= mp; b_p[s].z &= mp; b_p[s].w &= mp;
-      b_v[s].x &= mv; b_v[s].y &= mv; b_v[s].z &= mv; b_v[s].w &= mv;
-    }
-    C4_HSTAMP(1);
-#pragma unroll
-    for (int s = 0; s < kHeadSteps; s++) {
-      accp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_p[s]), __builtin_bit_cast(bf16x8, b_p[s]), accp, 0, 0, 0);
-      accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_v[s]), __builtin_bit_cast(bf16x8, b_v[s]), accv, 0, 0, 0);
-    }
-  }
-  C4_HSTAMP(2);
-  part[wave][0][lane] = accp;
-  part[wave][1][lane] = accv;
-  __syncthreads();
-  C4_HSTAMP(3);
-  if (wave < 2) {
-    // wavefront 0 finishes the policy tile, wavefront 1 the value tile: lane holds output column
-    // `row` of boards 4 kq .. 4 kq + 3
-    f32x4 sum = part[0][wave][lane];
-#pragma unroll
-    for (int w = 1; w < kHeadWaves; w++) sum += part[w][wave][lane];
-    const float bias = wave == 0 ? (row < 7 ? bp[row] : 0.f) : (row < 2 ? bv[row] : 0.f);
-#pragma unroll
-    for (int r = 0; r < 4; r++) tile[wave][4 * kq + r][row] = sum[r] + bias;
-  }
-  __syncthreads();
-  C4_HSTAMP(4);
-  if (threadIdx.x < kRows) {
-    const uint32_t b = threadIdx.x, gb = g0 + b;
-    if (gb < n_boards) {
-      float v[9];
-#pragma unroll
-      for (int o = 0; o < 7; o++) v[o] = tile[0][b][o];
-      v[7] = tile[1][b][0];
-      v[8] = tile[1][b][1];
-      float mx = v[0];
-#pragma unroll
-      for (int o = 1; o < 7; o++) mx = fmaxf(mx, v[o]);
-      float sm = 0.f;
-#pragma unroll
-      for (int o = 0; o < 7; o++) sm += expf(v[o] - mx);
-      const float lse = mx + logf(sm);
-#pragma unroll
-      for (int o = 0; o < 7; o++) logprobs[(size_t)gb * 7 + o] = v[o] - lse;
-      q[(size_t)gb * 2 + 0] = tanhf(v[7]);
-      q[(size_t)gb * 2 + 1] = tanhf(v[8]);
-    }
-  }
-#ifdef C4_HEAD_OUT_TRACE
-  C4_HSTAMP(5);
-  if (threadIdx.x == 0 && (blockIdx.x == 3 || blockIdx.x == 77))
-    printf("head_out wg %u: loads %llu  mfma %llu  partials+barrier %llu  sum+barrier %llu  softmax/tanh+stores %llu  (10 ns ticks)\n", blockIdx.x,
-           hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4]);
-#endif
+  __shared__ c4ho::Shared sh;
+  c4ho::head_out_block<kRows>(sh, hp, hv, wp, wv, bp, bv, n_boards, f8, sp8, sv8, logprobs, q, blockIdx.x);
 }
 
 }  // namespace

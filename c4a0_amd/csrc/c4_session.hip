@@ -35,6 +35,7 @@
 
 #include "../../include/c4a0_hip.h"
 #include "c4_device.hpp"
+#include "c4_head_out.hpp"
 #include "c4_host.hpp"
 
 #pragma clang fp contract(off)
@@ -106,13 +107,13 @@ constexpr uint32_t kWavesPerTimingHelper = 1024;   // stamps one timing helper w
 #define C4_STAMP(i, force)                                                                          \
   do {                                                                                              \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                       \
-    if (lane == 0) p.phase[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime() + ((force) & 0);  \
+    if (lane == 0) p.phase[(size_t)wave_index * 16 + (i)] = __builtin_amdgcn_s_memrealtime() + ((force) & 0);  \
   } while (0)
 // stamp by whichever lane is active first (second trip of the simulation loop: lane 0's game may have left it)
 #define C4_STAMP_ANY(i)                                                                             \
   do {                                                                                              \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                       \
-    if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) p.phase[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();  \
+    if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) p.phase[(size_t)wave_index * 16 + (i)] = __builtin_amdgcn_s_memrealtime();  \
   } while (0)
 #else
 #define C4_STAMP(i, force) do { } while (0)
@@ -481,41 +482,21 @@ C4_DEV void timing_helper(const Params& p, uint32_t lane) {
 #ifndef C4_STEP_WAVES
 #define C4_STEP_WAVES 4
 #endif
+// The step of the 8 games of ONE wavefront (the body of c4_step_kernel, and of the fused output + step kernel below).
+// `wave_index` = the wavefront's row in the per-wavefront arrays (games 8 wave_index .. + 7), `hot` = this lane's 16 bytes of its
+// game's state line, `nn_logit` / `nn_q` = the evaluator's outputs for the game (lane sub < 7: logit sub; q_penalty / q_no_penalty
+// on even / odd lanes), `t_start` = the wavefront's start stamp (timed launches).
 template <typename PlaneT, bool NOISE, bool CACHE>
-__global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_step_kernel(
-    // What the head of every wavefront's dependent chain needs, as leading SCALAR arguments (copies of p's fields): with
-    // -mllvm -amdgpu-kernarg-preload-count (build.py) they are in SGPRs when the wavefront starts, so the state line and
-    // the evaluator's outputs are requested at once instead of behind a scalar-load round trip to the kernarg segment.
-    Slot* __restrict__ a_slots, const float* __restrict__ a_logprobs, const float* __restrict__ a_q, uint32_t a_n_waves, uint32_t a_n_slots,
-    Params p) {
-  const uint32_t lane = threadIdx.x & 63;
+C4_DEV void step_body(const Params& p, const uint32_t wave_index, const uint32_t lane, const uint32_t n_slots, Slot* st, const uint4 hot,
+                      const float nn_logit, const float nn_q, const unsigned long long t_start) {
   const uint32_t sub = lane & 7;
   const int gbase = (int)(lane & ~7u);
-  const uint32_t g = blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
-
+  const uint32_t g = wave_index * 8 + (lane >> 3);
   uint32_t c_sims = 0, c_S = 0, c_K = 0, c_E = 0, c_moves = 0, c_done = 0, c_skipped = 0, c_samples = 0;   // this launch only
   uint32_t c_probes = 0, c_hits = 0;
-  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz device clock
-  C4_STAMP(0, 0);
-#ifdef C4_PHASE_STAMPS
-  if (lane == 0) for (int i = 9; i < 16; i++) p.phase[(size_t)blockIdx.x * 16 + i] = 0;
-#endif
-  if (blockIdx.x >= a_n_waves) { timing_helper(p, lane); return; }
-
-  const uint32_t gs = g < a_n_slots ? g : 0;
-  Slot* st = a_slots + gs;
-  // The game's state: ONE 128-byte line, 16 bytes per lane in one instruction; the evaluator's
-  // outputs for this game travel in the same round trip.
-  const uint4 hot = reinterpret_cast<const uint4*>(st)[sub];
-  const float nn_logit = a_logprobs[(size_t)gs * 7 + (sub < 7 ? sub : 6)];
-  const float nn_q = a_q[(size_t)gs * 2 + (sub & 1)];
-  // ... and they must LEAVE together: without this fence hipcc sinks the two evaluator loads into the
-  // `if (active)` below, i.e. behind the wait for the state line -- a second, serial memory round trip (plus the
-  // scalar loads of the two pointers) at the head of every wavefront's chain (round 3, found in the ISA).
-  __builtin_amdgcn_sched_barrier(0);
   // header words to every lane of the group (lane 3: state, arena, root ref, rng word)
   const uint32_t state0 = shfl_u32(hot.x, gbase + 3);
-  bool active = (g < a_n_slots) && (slot_status(state0) == kActive);
+  bool active = (g < n_slots) && (slot_status(state0) == kActive);
   uint4 line = hot;          // what goes back to the slot at the end
   bool store_line = false;
   // move RNG precompute (see the end of the kernel): what this game will need at its next move
@@ -827,9 +808,9 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
     add = sub == CTR_DONE ? c_done : add;
     add = sub == CTR_SKIPPED ? c_skipped : add;
     add = sub == CTR_SAMPLES ? c_samples : add;
-    if (add) atomicAdd(&p.wave_ctr[(size_t)blockIdx.x * CTR_N + sub], (unsigned long long)add);
+    if (add) atomicAdd(&p.wave_ctr[(size_t)wave_index * CTR_N + sub], (unsigned long long)add);
     const uint32_t add2 = sub == 0 ? c_probes : (sub == 1 ? c_hits : 0u);
-    if (CACHE && add2) atomicAdd(&p.wave_ctr[(size_t)blockIdx.x * CTR_N + CTR_PROBES + sub], (unsigned long long)add2);
+    if (CACHE && add2) atomicAdd(&p.wave_ctr[(size_t)wave_index * CTR_N + CTR_PROBES + sub], (unsigned long long)add2);
   }
   // ---------------- move RNG, off the critical path ------------------------------------------
   // The launch lasts as long as its slowest wavefront, and that is one with a MOVING game.  The
@@ -842,10 +823,74 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
   if (store_line) reinterpret_cast<uint4*>(st)[sub] = line;
   C4_STAMP(8, 0);
   if (lane == 0 && p.seq) {
-    unsigned long long* my = p.stamps + ((size_t)(p.seq & 1) * p.n_waves + blockIdx.x) * 2;
+    unsigned long long* my = p.stamps + ((size_t)(p.seq & 1) * p.n_waves + wave_index) * 2;
     my[0] = t_start;
     my[1] = __builtin_amdgcn_s_memrealtime();
   }
+}
+
+template <typename PlaneT, bool NOISE, bool CACHE>
+__global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_step_kernel(
+    // What the head of every wavefront's dependent chain needs, as leading SCALAR arguments (copies of p's fields): with
+    // -mllvm -amdgpu-kernarg-preload-count (build.py) they are in SGPRs when the wavefront starts, so the state line and
+    // the evaluator's outputs are requested at once instead of behind a scalar-load round trip to the kernarg segment.
+    Slot* __restrict__ a_slots, const float* __restrict__ a_logprobs, const float* __restrict__ a_q, uint32_t a_n_waves, uint32_t a_n_slots,
+    Params p) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t sub = lane & 7;
+  const uint32_t wave_index = blockIdx.x;
+  const uint32_t g = wave_index * 8 + (lane >> 3);
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz device clock
+  C4_STAMP(0, 0);
+#ifdef C4_PHASE_STAMPS
+  if (lane == 0) for (int i = 9; i < 16; i++) p.phase[(size_t)wave_index * 16 + i] = 0;
+#endif
+  if (blockIdx.x >= a_n_waves) { timing_helper(p, lane); return; }
+
+  const uint32_t gs = g < a_n_slots ? g : 0;
+  Slot* st = a_slots + gs;
+  // The game's state: ONE 128-byte line, 16 bytes per lane in one instruction; the evaluator's
+  // outputs for this game travel in the same round trip.
+  const uint4 hot = reinterpret_cast<const uint4*>(st)[sub];
+  const float nn_logit = a_logprobs[(size_t)gs * 7 + (sub < 7 ? sub : 6)];
+  const float nn_q = a_q[(size_t)gs * 2 + (sub & 1)];
+  // ... and they must LEAVE together: without this fence hipcc sinks the two evaluator loads into the
+  // `if (active)` below, i.e. behind the wait for the state line -- a second, serial memory round trip (plus the
+  // scalar loads of the two pointers) at the head of every wavefront's chain (round 3, found in the ISA).
+  __builtin_amdgcn_sched_barrier(0);
+  step_body<PlaneT, NOISE, CACHE>(p, wave_index, lane, a_n_slots, st, hot, nn_logit, nn_q, t_start);
+}
+
+// ------------------------------------------------------------------------------------------
+// The heads' output layers AND the step in one launch (c4_session_step_head_out).  A workgroup of the output kernel owns
+// 16 boards -- the games of exactly two step wavefronts -- so nothing crosses a workgroup: wavefronts 0 and 1 request
+// their games' state lines at the very start (the round trip is over long before the outputs exist), all six compute the
+// outputs (c4_head_out.hpp: the same code as the stand-alone kernel, the same bits; the outputs still go to the bound
+// logprobs / q tensors for whoever watches them), and wavefronts 0 and 1 go on as the step of their 8 games each, taking
+// the logits from LDS.  One launch boundary, the step kernel's argument fetch and both of its head-of-chain round trips
+// leave a session's per-round chain.  Default configuration only (no Dirichlet noise, no evaluation cache, no per-launch
+// timing): everything else keeps the two launches.
+// ------------------------------------------------------------------------------------------
+template <typename PlaneT>
+__global__ __launch_bounds__(64 * c4ho::kHeadWaves, 1) void c4_out_step_kernel(
+    const uint4* __restrict__ hp, const uint4* __restrict__ hv, const uint4* __restrict__ wp, const uint4* __restrict__ wv,
+    const float* __restrict__ bp, const float* __restrict__ bv, Slot* __restrict__ a_slots, uint32_t a_n_slots, uint32_t f8, uint32_t sp8, uint32_t sv8,
+    Params p) {
+  __shared__ c4ho::Shared sh;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7;
+  const uint32_t wave_index = blockIdx.x * 2 + wave;                    // wavefronts 0 and 1: games 16 blockIdx.x + 8 wave + (lane >> 3)
+  const uint32_t g = wave_index * 8 + (lane >> 3);
+  const uint32_t gs = g < a_n_slots ? g : 0;
+  Slot* st = a_slots + gs;
+  uint4 hot = make_uint4(0, 0, 0, 0);
+  if (wave < 2) hot = reinterpret_cast<const uint4*>(st)[sub];          // in flight under the output layers
+  c4ho::head_out_block<16>(sh, hp, hv, wp, wv, bp, bv, a_n_slots, f8, sp8, sv8, const_cast<float*>(p.logprobs), const_cast<float*>(p.q), blockIdx.x);
+  __syncthreads();
+  if (wave >= 2 || wave_index >= p.n_waves) return;
+  const uint32_t b = wave * 8 + (lane >> 3);
+  const float nn_logit = sh.res[b][sub < 7 ? sub : 6];
+  const float nn_q = sh.res[b][7 + (sub & 1)];
+  step_body<PlaneT, false, false>(p, wave_index, lane, a_n_slots, st, hot, nn_logit, nn_q, 0ull);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1554,6 +1599,31 @@ int c4_session_step(c4_session* s) {
   } while (0)
   C4_LAUNCH_STEP(c4_step_kernel);
 #undef C4_LAUNCH_STEP
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
+int c4_session_step_head_out(c4_session* s, const void* hidden_policy_dev, const void* hidden_value_dev, const void* w_policy_dev,
+                             const void* w_value_dev, const float* b_policy_dev, const float* b_value_dev, uint32_t features,
+                             uint32_t policy_row_stride, uint32_t value_row_stride) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  if (!s->bound || !s->have_games) return fail(C4_ERR_NOT_BOUND, "bind_io and set_games must precede step");
+  if (!hidden_policy_dev || !hidden_value_dev || !w_policy_dev || !w_value_dev || !b_policy_dev || !b_value_dev)
+    return fail(C4_ERR_BAD_ARG, "c4_session_step_head_out: null argument");
+  if (features % 8 != 0 || policy_row_stride % 8 != 0 || value_row_stride % 8 != 0 || (features / 8) % (4 * c4ho::kHeadSteps * c4ho::kHeadWaves) != 0)
+    return fail(C4_ERR_BAD_ARG, "c4_session_step_head_out: features must be a multiple of 1 344 (42 x 32 channels) and the row strides of 8 elements");
+  if (s->p.dir_eps > 0.0f || s->p.cache != nullptr || s->timing)
+    return fail(C4_ERR_BAD_ARG, "c4_session_step_head_out: the fused launch exists for the default configuration only (no Dirichlet noise, no evaluation "
+                                "cache, per-launch timing off): call c4_head_out_bf16 and c4_session_step");
+  C4_ON_DEVICE(s->cfg.device);
+  s->p.seq = 0;
+  const uint32_t groups = (s->p.n_slots + 15) / 16;
+  auto launch = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(groups), dim3(64 * c4ho::kHeadWaves), 0, s->stream, (const uint4*)hidden_policy_dev, (const uint4*)hidden_value_dev,
+                       (const uint4*)w_policy_dev, (const uint4*)w_value_dev, b_policy_dev, b_value_dev, s->p.slots, s->p.n_slots, features / 8,
+                       policy_row_stride / 8, value_row_stride / 8, s->p);
+  };
+  if (s->cfg.planes_dtype == 0) launch(c4_out_step_kernel<float>); else launch(c4_out_step_kernel<uint16_t>);
   HIP_TRY(hipGetLastError());
   return C4_OK;
 }

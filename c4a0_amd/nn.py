@@ -243,8 +243,10 @@ class InferenceNet:
         return x.reshape(x.shape[0], -1)
 
     @torch.no_grad()
-    def forward(self, planes: torch.Tensor, out_logprobs: Optional[torch.Tensor] = None,
-                out_q: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward_hidden(self, planes: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Everything but the heads' output layers: planes -> (policy head's last hidden activations, value head's), bf16
+        [G, F] row views (column stride 1).  The output layers follow in `forward`, or inside the session's fused output +
+        step launch (DeviceSession.round, c4_session_step_head_out)."""
         hook = self.stage_hook
         if hook is not None:
             hook(0)
@@ -274,12 +276,27 @@ class InferenceNet:
                 hook(3 + i)      # after each narrow policy layer (capture_pair's offset_stage)
         for w, b in val_rest:
             v = self._linear_relu(v, w, b)
+        return p, v
+
+    @property
+    def fused_step_ok(self) -> bool:
+        """The session may run this evaluator's output layers inside its step launch (c4_session_step_head_out)."""
+        return bool(self.hip_tower) and (42 * self.channels) % 1344 == 0
+
+    def head_out_operands(self):
+        """(w_policy, w_value, b_policy f32, b_value f32) of the output layers, as the HIP output kernels take them."""
+        return self.pol_w[-1], self.val_w[-1], self.pol_b32, self.val_b32
+
+    @torch.no_grad()
+    def forward(self, planes: torch.Tensor, out_logprobs: Optional[torch.Tensor] = None,
+                out_q: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        p, v = self.forward_hidden(planes)
         if self.hip_tower:
             # both output layers + log-softmax + tanh in one HIP launch, written in place
             from ._lib import check
             import ctypes as C
 
-            g = x.shape[0]
+            g = p.shape[0]
             lp = out_logprobs if out_logprobs is not None else torch.empty((g, 7), dtype=torch.float32, device=self.device)
             q = out_q if out_q is not None else torch.empty((g, 2), dtype=torch.float32, device=self.device)
             assert p.stride(1) == 1 and v.stride(1) == 1

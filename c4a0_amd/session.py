@@ -55,6 +55,7 @@ class DeviceSession:
         self.n_games = 0
         self.rows = self.n_slots          # slots a step launches / rows the evaluator computes (compact() narrows it)
         self._bound_stream = None
+        self._timing, self._extensions = True, False   # what c4_session_step_head_out refuses: per-launch timing, noise / cache
 
     # ---------------------------------------------------------------- lifetime
     def close(self):
@@ -93,6 +94,7 @@ class DeviceSession:
     def set_dirichlet(self, alpha: float, epsilon: float):
         """Extension (not in the reference): Dirichlet noise on the priors of every search root."""
         check(self.L.c4_session_set_dirichlet(self._h, float(alpha), float(epsilon)))
+        self._extensions = self._extensions or float(epsilon) > 0.0
 
     def set_eval_cache(self, n_entries: int, max_sims_per_step: int = 0):
         """Extension (not in the reference, off by default): keep the evaluator's outputs by position in a
@@ -100,6 +102,7 @@ class DeviceSession:
         that simulation in the same launch instead of using an evaluator row (c4_session_set_eval_cache).
         Needs an evaluator that is a deterministic function of the position.  Call before start()."""
         check(self.L.c4_session_set_eval_cache(self._h, int(n_entries), int(max_sims_per_step)))
+        self._extensions = self._extensions or int(n_entries) > 0
 
     def bind_leaf_models(self) -> torch.Tensor:
         """int64[n_slots] tensor that start()/step() fill with the model id to evaluate each leaf with."""
@@ -115,6 +118,25 @@ class DeviceSession:
 
     def set_timing(self, enable: bool):
         check(self.L.c4_session_set_timing(self._h, 1 if enable else 0))
+        self._timing = bool(enable)
+
+    def round(self, evaluator: DeviceEvaluator):
+        """One lock-step round: evaluate the leaves, step every game.  With an evaluator that offers its hidden activations
+        (c4a0_amd.nn.InferenceNet) and the session in its default configuration with per-launch timing off (every HIP-graph
+        capture), the heads' output layers run inside the step's launch (c4_session_step_head_out: one launch fewer on the
+        round's chain, same bits); otherwise evaluate() then step()."""
+        if (self.fuse_output_step and not self._timing and not self._extensions and getattr(self, "leaf_models", None) is None
+                and getattr(evaluator, "fused_step_ok", False)):
+            r = self.rows
+            p, v = evaluator.forward_hidden(self.planes if r == self.n_slots else self.planes[:r])
+            wp, wv, bp, bv = evaluator.head_out_operands()
+            assert p.stride(1) == 1 and v.stride(1) == 1 and p.shape[0] == r
+            check(self.L.c4_session_step_head_out(self._h, C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(wp.data_ptr()),
+                                                  C.c_void_p(wv.data_ptr()), C.c_void_p(bp.data_ptr()), C.c_void_p(bv.data_ptr()),
+                                                  p.shape[1], p.stride(0), v.stride(0)))
+            return
+        self.evaluate(evaluator)
+        self.step()
 
     def capture_steps(self, evaluator: DeviceEvaluator, steps_per_graph: int = 8,
                       stream: Optional[torch.cuda.Stream] = None) -> "torch.cuda.CUDAGraph":
@@ -140,8 +162,7 @@ class DeviceSession:
         with torch.cuda.graph(graph, stream=stream, capture_error_mode=CAPTURE_ERROR_MODE):
             self.bind(torch.cuda.current_stream(self.device))
             for _ in range(steps_per_graph):
-                self.evaluate(evaluator)
-                self.step()
+                self.round(evaluator)
         self.bind(main)
         return graph
 
@@ -228,6 +249,7 @@ class DeviceSession:
         if q_out.data_ptr() != q.data_ptr():
             q.copy_(q_out.reshape(r, 2))
 
+    fuse_output_step = True    # round(): the heads' output layers inside the step's launch where the evaluator allows it (False: A/B)
     NARROW_CHECK_ROUNDS = 64   # lock-step rounds between two looks at the tail (a stream synchronisation each)
 
     def wants_narrowing(self, multiple: int = 256, asynchronous: bool = False) -> bool:
@@ -388,12 +410,10 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
 
                 evaluator.stage_hook = hook_a
                 with torch.cuda.stream(s0):
-                    a.evaluate(evaluator)
-                    a.step()
+                    a.round(evaluator)
                 evaluator.stage_hook = hook_b
                 with torch.cuda.stream(s1):
-                    b.evaluate(evaluator)
-                    b.step()
+                    b.round(evaluator)
                 ev_b_prev = ev_b
             s0.wait_stream(s1)                                  # join
     finally:

@@ -24,10 +24,10 @@ extern "C" {
 #endif
 
 /* Version of THIS interface: bumped whenever a signature or a struct layout below changes (version 3 added `config` in the
- * middle of c4_conv_tower_bf16's arguments).  A consumer compiled against this header checks it once at start-up --
+ * middle of c4_conv_tower_bf16's arguments, version 5 c4_session_step_head_out).  A consumer compiled against this header checks it once at start-up --
  * `if (c4_abi_version() != C4_ABI_VERSION) refuse` -- because the dynamic linker compares names, not signatures
  * (tests/abi_consumer*.c and c4a0_amd/_lib.py do).  No reference counterpart: the reference's boundary is PyO3. */
-#define C4_ABI_VERSION 4
+#define C4_ABI_VERSION 5
 
 #define C4_N_COLS 7          /* rust/src/c4r.rs:45, lib.rs:28 */
 #define C4_N_ROWS 6          /* rust/src/c4r.rs:44, lib.rs:29 */
@@ -173,6 +173,17 @@ int c4_session_start(c4_session* s);
  * root has n_mcts_iterations visits (make_random_move, mcts.rs:214-222), finish and replace
  * finished games, select the next leaves and write them to planes_dev.  Asynchronous. */
 int c4_session_step(c4_session* s);
+
+/* c4_head_out_bf16 (below) + c4_session_step as ONE launch: the heads' output layers (nn.py:84-85, 98-99) are computed by
+ * workgroups of 16 boards whose first two wavefronts go on as the step of those 16 games (mcts.rs:83-108, self_play.rs:268-323):
+ * one launch boundary and the step's argument fetch / state-line round trip leave the per-round chain.  The outputs are also
+ * written to the bound logprobs / q tensors, and every result equals the two-launch form bit for bit (same code).  Operands as
+ * for c4_head_out_bf16, rows = the session's current width, stream = the session's.  Default configuration only: returns
+ * C4_ERR_BAD_ARG when Dirichlet noise, the evaluation cache or per-launch timing (c4_session_set_timing) is on, or when
+ * `features` is not a multiple of 1 344 -- callers then use the two entry points. */
+int c4_session_step_head_out(c4_session* s, const void* hidden_policy_dev, const void* hidden_value_dev, const void* w_policy_dev,
+                             const void* w_value_dev, const float* b_policy_dev, const float* b_value_dev, uint32_t features,
+                             uint32_t policy_row_stride, uint32_t value_row_stride);
 
 /* Per-launch device-clock timing of the step kernel (c4_counters.step_kernel_ns) needs a launch
  * sequence number in the kernel arguments, which a HIP-graph capture would freeze: switch it
