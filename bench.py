@@ -155,11 +155,8 @@ def whole_job(args, device, real_stdout):
     n_games, n_iter = args.whole_job_games, args.whole_job_n_mcts
     reqs = [c4a0_amd.GameMetadata(i, 0, 0) for i in range(n_games)]
 
-    def cb(_model_id, x):   # the shape of ConnectFourNet.forward_numpy (nn.py:119-130): H2D, forward, 3 x D2H
-        with torch.no_grad():
-            lp, q = net(torch.from_numpy(x).to(device))
-            lp, q = lp.float().cpu().numpy(), q.float().cpu().numpy()
-        return np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
+    def cb(_model_id, x):   # exactly the reference caller's callback (training.py:179-189): lambda model_id, x: model.forward_numpy(x)
+        return net.forward_numpy(x)
 
     out, ref = {}, None
     modes = (("device_mode", dict(evaluator=net)), ("device_callback_wrapper", dict(py_eval_pos_cb=c4a0_amd.DeviceCallback(net, device))),

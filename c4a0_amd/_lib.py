@@ -87,6 +87,7 @@ SIGNATURES = {
     "c4_session_leaf_keys": (C.c_int, [_vp, _vp]),
     "c4_session_unique_leaves": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "c4_session_scatter_outputs": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
+    "c4_session_step_gather": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
     "c4_session_leaves": (C.c_int, [_vp, _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint32), _P(C.c_uint32)]),
     "c4_pos_ops": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     "c4_encode_planes": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp]),

@@ -73,7 +73,7 @@ class _CallbackEvaluator:
         self.h_out = torch.empty((g, 9), dtype=torch.float32).pin_memory()
         self.nn_positions = 0
 
-    def __call__(self, _planes: torch.Tensor):
+    def __call__(self, _planes: torch.Tensor, fused_step: bool = False):
         s, C = self.s, self._C
         g = s.n_slots
         # A FRESH pinned array per step (PyTorch's caching host allocator: no system call after warm-up), as the
@@ -111,8 +111,22 @@ class _CallbackEvaluator:
                 self.nn_positions += j - i
         # h_out is read by the kernel on the session's stream; the next write to it happens after the next step's
         # synchronisation above, which that kernel precedes
+        if fused_step:   # the step kernel itself takes every game's answers from its row (c4_session_step_gather): one launch less
+            self._check(s.L.c4_session_step_gather(s._h, C.c_void_p(self.inverse.data_ptr()), C.c_void_p(self.h_out.data_ptr()), n_u))
+            return None
         self._check(s.L.c4_session_scatter_outputs(s._h, C.c_void_p(self.inverse.data_ptr()), C.c_void_p(self.h_out.data_ptr()), n_u))
         return s.logprobs, s.q
+
+    gather_step = True   # round(): scatter + step as one launch (False: A/B)
+
+    def round(self):
+        """evaluate + step for DeviceSession.round: the answers are handed over inside the step's launch."""
+        if not self.gather_step:
+            self(None)
+            self.s.step()
+            return
+        if self(None, fused_step=True) is not None:      # every resident game had finished: nothing was evaluated, a plain (idle) step
+            self.s.step()
 
 
 class _MultiModelEvaluator:

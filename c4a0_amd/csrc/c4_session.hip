@@ -861,6 +861,33 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
   step_body<PlaneT, NOISE, CACHE>(p, wave_index, lane, a_n_slots, st, hot, nn_logit, nn_q, t_start);
 }
 
+// c4_session_scatter_outputs + c4_session_step as ONE launch (callback mode, c4_session_step_gather): a game takes its evaluator
+// outputs from row inverse[g] of the callback's answers (7 log-probabilities, q_penalty, q_no_penalty per row; pinned host memory
+// or device memory) instead of from the bound tensors -- one launch and one boundary less per callback round trip.  The bound
+// logprobs / q tensors are NOT updated by this form (callers that watch them use the two entry points).
+template <typename PlaneT, bool NOISE, bool CACHE>
+__global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_step_gather_kernel(
+    Slot* __restrict__ a_slots, const float* __restrict__ a_answers, const uint32_t* __restrict__ a_inverse, uint32_t a_n_unique, uint32_t a_n_waves,
+    uint32_t a_n_slots, Params p) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t sub = lane & 7;
+  const uint32_t wave_index = blockIdx.x;
+  const uint32_t g = wave_index * 8 + (lane >> 3);
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  C4_STAMP(0, 0);
+  if (blockIdx.x >= a_n_waves) { timing_helper(p, lane); return; }
+  const uint32_t gs = g < a_n_slots ? g : 0;
+  Slot* st = a_slots + gs;
+  const uint4 hot = reinterpret_cast<const uint4*>(st)[sub];
+  const uint32_t row = a_inverse[gs];
+  float nn_logit = 0.f, nn_q = 0.f;
+  if (row < a_n_unique) {                                           // (idle slots have no row: their values are never used)
+    nn_logit = a_answers[(size_t)row * 9 + (sub < 7 ? sub : 6)];
+    nn_q = a_answers[(size_t)row * 9 + 7 + (sub & 1)];
+  }
+  step_body<PlaneT, NOISE, CACHE>(p, wave_index, lane, a_n_slots, st, hot, nn_logit, nn_q, t_start);
+}
+
 // ------------------------------------------------------------------------------------------
 // The heads' output layers AND the step in one launch (c4_session_step_head_out).  A workgroup of the output kernel owns
 // 16 boards -- the games of exactly two step wavefronts -- so nothing crosses a workgroup: wavefronts 0 and 1 request
@@ -1564,7 +1591,9 @@ int c4_session_start(c4_session* s) {
   return C4_OK;
 }
 
-int c4_session_step(c4_session* s) {
+static int device_view(const void* ptr, int device, const char* what, void** out);   // defined with the callback-mode entry points below
+
+static int launch_step(c4_session* s, const uint32_t* inverse, const float* answers, uint32_t n_unique) {
   if (!s) return fail(C4_ERR_BAD_ARG, "null session");
   if (!s->bound || !s->have_games) return fail(C4_ERR_NOT_BOUND, "bind_io and set_games must precede step");
   C4_ON_DEVICE(s->cfg.device);
@@ -1586,21 +1615,38 @@ int c4_session_step(c4_session* s) {
   auto launch = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(s->n_waves + helpers), dim3(64), lds_pad, s->stream, s->p.slots, s->p.logprobs, s->p.q, s->p.n_waves, s->p.n_slots, s->p);
   };
+  auto launch_gather = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(s->n_waves + helpers), dim3(64), lds_pad, s->stream, s->p.slots, answers, inverse, n_unique, s->p.n_waves, s->p.n_slots, s->p);
+  };
   const bool f32 = s->cfg.planes_dtype == 0;
-#define C4_LAUNCH_STEP(KERNEL)                                                                                       \
+#define C4_LAUNCH_STEP(KERNEL, LAUNCH)                                                                               \
   do {                                                                                                               \
     if (f32) {                                                                                                       \
-      if (noise) { if (cache) launch(KERNEL<float, true, true>); else launch(KERNEL<float, true, false>); }          \
-      else       { if (cache) launch(KERNEL<float, false, true>); else launch(KERNEL<float, false, false>); }        \
+      if (noise) { if (cache) LAUNCH(KERNEL<float, true, true>); else LAUNCH(KERNEL<float, true, false>); }          \
+      else       { if (cache) LAUNCH(KERNEL<float, false, true>); else LAUNCH(KERNEL<float, false, false>); }        \
     } else {                                                                                                         \
-      if (noise) { if (cache) launch(KERNEL<uint16_t, true, true>); else launch(KERNEL<uint16_t, true, false>); }    \
-      else       { if (cache) launch(KERNEL<uint16_t, false, true>); else launch(KERNEL<uint16_t, false, false>); }  \
+      if (noise) { if (cache) LAUNCH(KERNEL<uint16_t, true, true>); else LAUNCH(KERNEL<uint16_t, true, false>); }    \
+      else       { if (cache) LAUNCH(KERNEL<uint16_t, false, true>); else LAUNCH(KERNEL<uint16_t, false, false>); }  \
     }                                                                                                                \
   } while (0)
-  C4_LAUNCH_STEP(c4_step_kernel);
+  if (inverse) C4_LAUNCH_STEP(c4_step_gather_kernel, launch_gather); else C4_LAUNCH_STEP(c4_step_kernel, launch);
 #undef C4_LAUNCH_STEP
   HIP_TRY(hipGetLastError());
   return C4_OK;
+}
+
+int c4_session_step(c4_session* s) { return launch_step(s, nullptr, nullptr, 0); }
+
+int c4_session_step_gather(c4_session* s, const uint32_t* inverse_dev, const float* answers, uint32_t n_unique) {
+  if (!s || !inverse_dev || (!answers && n_unique)) return fail(C4_ERR_BAD_ARG, "null argument");
+  if (!s->bound) return fail(C4_ERR_NOT_BOUND, "c4_session_step_gather: bind_io first");
+  void *inv = nullptr, *ans = nullptr;
+  {
+    C4_ON_DEVICE(s->cfg.device);
+    if (int rc = device_view(inverse_dev, s->cfg.device, "c4_session_step_gather: inverse_dev", &inv)) return rc;
+    if (answers) if (int rc = device_view(answers, s->cfg.device, "c4_session_step_gather: answers", &ans)) return rc;
+  }
+  return launch_step(s, (const uint32_t*)inv, (const float*)ans, n_unique);
 }
 
 int c4_session_step_head_out(c4_session* s, const void* hidden_policy_dev, const void* hidden_value_dev, const void* w_policy_dev,

@@ -135,6 +135,9 @@ class DeviceSession:
                                                   C.c_void_p(wv.data_ptr()), C.c_void_p(bp.data_ptr()), C.c_void_p(bv.data_ptr()),
                                                   p.shape[1], p.stride(0), v.stride(0)))
             return
+        if hasattr(evaluator, "round") and getattr(evaluator, "s", None) is self:   # the numpy-callback evaluator: answers handed over in the step's launch
+            evaluator.round()
+            return
         self.evaluate(evaluator)
         self.step()
 
@@ -305,10 +308,12 @@ class DeviceSession:
                 steps += steps_per_graph
                 chunk_end = True
             else:
-                self.evaluate(evaluator)
                 if on_step is not None:   # observers see the evaluator outputs before the step consumes them
+                    self.evaluate(evaluator)
                     on_step(steps)
-                self.step()
+                    self.step()
+                else:
+                    self.round(evaluator)
                 steps += 1
                 chunk_end = steps % poll_every == 0
             if chunk_end:

@@ -255,6 +255,12 @@ int c4_session_unique_leaves(c4_session* s, uint32_t* inverse_dev, float* rows_o
  * the caller keeps `answers` untouched until the stream has passed this point. */
 int c4_session_scatter_outputs(c4_session* s, const uint32_t* inverse_dev, const float* answers, uint32_t n_unique);
 
+/* c4_session_scatter_outputs + c4_session_step as ONE launch: every game takes its evaluator outputs from row inverse_dev[slot] of
+ * `answers` (as for c4_session_scatter_outputs: device or pinned host memory, 9 floats per row) inside the step kernel itself
+ * (self_play.rs:222-236 hands each waiting game its result, :268-323 runs its job).  The bound logprobs / q tensors are NOT
+ * updated: callers that watch them keep the two entry points.  Every configuration of the session (noise, cache, timing). */
+int c4_session_step_gather(c4_session* s, const uint32_t* inverse_dev, const float* answers, uint32_t n_unique);
+
 /* Leaf position currently waiting for the evaluator, per slot (MctsGame::leaf_pos, mcts.rs:64-66);
  * status[g] = 1 active / 0 idle, ordinal[g] = index of the slot's game in reqs.  Host arrays of
  * n_slots (any may be NULL).  Synchronises.  Used by the numpy-callback compatibility mode. */

@@ -76,6 +76,15 @@ def test_restatement_matches_the_reference_at_the_hip_kernels_width():
     assert 0.1 < z["policy_logprobs"].std(0).min() and np.abs(z["q_penalty"]).max() < 0.999
 
 
+def test_forward_numpy_on_the_cpu_path_matches_reference_outputs():
+    """InferenceNet.forward_numpy (reference nn.py:119-130) without a HIP device: the plain PyTorch path, same contract."""
+    z, cfg, model = _load()
+    net = InferenceNet(model, torch.device("cpu"), dtype=torch.float32)
+    lp, qp, qn = net.forward_numpy(z["x"])
+    assert lp.dtype == np.float32 and lp.shape == (24, 7) and qp.shape == (24,) and lp.flags["C_CONTIGUOUS"] and qn.flags["C_CONTIGUOUS"]
+    assert np.abs(lp - z["policy_logprobs"]).max() <= TOL and np.abs(qp - z["q_penalty"]).max() <= TOL and np.abs(qn - z["q_no_penalty"]).max() <= TOL
+
+
 def test_flops_per_leaf_matches_survey():
     # SURVEY 8d: 1x32 16.1 M; 4x32 20.7 M; 8x64 107.5 M
     assert round(flops_per_leaf(ModelConfig(1, 32, 4, 2)) / 1e6, 1) == 16.1
