@@ -622,6 +622,8 @@ def main():
                            if args.eval_cache else None),
             "sims_per_game": sims / max(1.0, games),
             "roofline": {"bound": "hbm", "kernel": "c4_step_kernel (expand+backup+move+select+encode, fused)",
+                         "measured_on": "the instrumented launches after the timed region (stand-alone c4_step_kernel, per-launch timing on); inside the "
+                                        "timed region the same step_body runs as the second half of c4_out_step_kernel, behind the heads' output layers",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic,
                          "traffic_source": "profiles/step_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, corrected per MI355X_MICROARCH.md); not re-measured in this run",

@@ -6,7 +6,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 benc
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv; rm -rf $O/stats
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --rounds-per-step 64 --preroll 640 --instrumented-steps 300 --no-cpu-baseline --no-other-configs > $O/pmc_$c.json 2> $O/pmc_$c.err
-  python tools/profile/summarize_pmc.py $O/pmc_$c c4_step_kernel 800 > $O/traffic_$c.json
+  python tools/profile/summarize_pmc.py $O/pmc_$c c4_step_kernel 20 > $O/traffic_$c.json   # the 300 instrumented launches (the timed region runs the step inside c4_out_step_kernel)
   rm -rf $O/pmc_$c
 done
 python tools/tree_roofline.py --games 2048,4096,16384,65536,131072 > $O/tree_sweep.json 2> $O/tree_sweep.err
