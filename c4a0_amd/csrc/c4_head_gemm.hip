@@ -164,15 +164,23 @@ __device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[TN][TM], cons
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(C4_GEMM_ARGS) {
+// NLOAD = 0: every wavefront computes AND issues its share of the DMA pieces (interleaved with its MFMAs).
+// NLOAD > 0: wave specialisation -- WM x WN wavefronts compute (fragment reads + MFMAs only), NLOAD more wavefronts do nothing
+// but issue the DMA pieces and wait for them; the k-tile barrier is the only thing the two kinds share.  Why: a CU accepts one
+// 1 KB DMA piece per ~25 cycles (tools/feed_lab: 40 pieces per k-tile = 1 000 cycles with nothing else running) and an issuing
+// wavefront is held 60-185 cycles per piece; in the NLOAD = 0 form those cycles come out of the wavefronts that should be
+// issuing MFMAs (768 cycles of matrix work per k-tile and SIMD take 1 270-1 320).  Same LDS image, same fragment reads, same
+// MFMA order: same bits.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW, int NLOAD = 0>
+__global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_kernel(C4_GEMM_ARGS) {
   C4_GEMM_UNPACK();
-  constexpr int kWaves = WM * WN;
+  constexpr int kWaves = WM * WN;                             // computing wavefronts
+  constexpr int kIssuers = NLOAD ? NLOAD : kWaves;            // wavefronts that issue DMA pieces
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;        // 16 x 16 output tiles per wavefront
   constexpr int kStageBytes = (BM + BN) * BK * 2;
   constexpr int kChunks = (BM + BN) / 8;                      // 1 KB DMA pieces (8 rows x 128 bytes) per k-tile
-  constexpr int L = kChunks / kWaves;                         // pieces per wavefront per k-tile
-  static_assert(kChunks % kWaves == 0, "every wavefront issues the same number of loads per k-tile (counted waits)");
+  constexpr int L = kChunks / kIssuers;                       // pieces per issuing wavefront per k-tile
+  static_assert(kChunks % kIssuers == 0, "every issuing wavefront issues the same number of loads per k-tile (counted waits)");
   static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "wave tiles are multiples of 16");
   static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
@@ -181,8 +189,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(C4_GEM
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave % WM, wn = wave / WM;
+  const int wm = wave % WM, wn = (wave / WM) % WN;            // (a loader wavefront's are unused)
   const int li = lane & 15, lg = lane >> 4;
+  const bool is_loader = NLOAD != 0 && wave >= kWaves;
+  const int issuer = NLOAD ? wave - kWaves : wave;            // this wavefront's index among the issuing ones
 
   // ---- which tile: blocks b and b + 8 share an XCD (round-robin dispatch; speed only).  Give each
   // XCD a rectangle of tiles so that its private L2 sees each X row block and W column block once.
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(C4_GEM
   const int r8 = lane >> 3, slot = lane & 7;
 #pragma unroll
   for (int i = 0; i < L; i++) {
-    const int c = wave + kWaves * i;
+    const int c = (issuer < 0 ? 0 : issuer) + kIssuers * i;
     if (c < BM / 8) {
       const int row = c * 8 + r8;
       int gr = tm0 + row;
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(C4_GEM
   const int KT = (int)p.K / BK;
   auto issue_one = [&](int kt, int i) __attribute__((always_inline)) {
     uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
-    const int c = wave + kWaves * i;
+    const int c = (issuer < 0 ? 0 : issuer) + kIssuers * i;
     const uint32_t tail = kt >= KT ? 0x80000000u : 0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds((c < BM / 8) ? x_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)(st + c * 1024), 16,
                                              (int)(src_off[i] | tail), kt * (BK * 2), 0, 0);
@@ -237,6 +247,18 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(C4_GEM
 #pragma unroll
     for (int i = 0; i < L; i++) issue_one(kt, i);
   };
+  if (NLOAD != 0 && is_loader) {
+    // ---- a loader wavefront: k-tiles NSTAGE - 1 ahead of the computing wavefronts, one barrier per k-tile with them
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; s++) issue(s);
+    for (int kt = 0; kt < KT; kt++) {
+      wait_vmcnt<(NSTAGE - 2) * L>();                           // my pieces of k-tile kt have landed
+      __builtin_amdgcn_s_barrier();                             // ... everybody's have; everybody has left buffer (kt - 1) % NSTAGE
+      issue(kt + NSTAGE - 1);
+    }
+    wait_vmcnt<0>();                                            // nothing may land in LDS that was given away
+    return;
+  }
 
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -254,15 +276,17 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(C4_GEM
   f32x4 bias_v[TN];
 #pragma unroll
   for (int a = 0; a < TN; a++) bias_v[a] = *reinterpret_cast<const f32x4*>(p.bias + tn0 + wn * (BN / WN) + a * 16 + 4 * lg);
+  if (NLOAD == 0) {
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; s++) issue(s);
+    for (int s = 0; s < NSTAGE - 1; s++) issue(s);
+  }
 
   C4_GSTAMP(1);
   C4_CLK_BEGIN();
   for (int kt = 0; kt < KT; kt++) {
     // k-tile kt must have landed; the NSTAGE - 2 younger ones stay in flight (the same count in every iteration:
     // see issue_one for the pieces past the last k-tile)
-    wait_vmcnt<(NSTAGE - 2) * L>();
+    if (NLOAD == 0) wait_vmcnt<(NSTAGE - 2) * L>();
     __builtin_amdgcn_s_barrier();                               // everybody's pieces of kt landed; everybody left buffer (kt - 1) % NSTAGE
 #ifdef C4_GEMM_CLOCK
     if (kt == 0) C4_GSTAMP(2);
@@ -301,15 +325,17 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm_kernel(C4_GEM
       for (int r = a * kPerStep; r < (a + 1) * kPerStep && r < TN + TM; r++) {
         if (r < TM) rd_x(1, r); else rd_w(1, r - TM);
       }
+      if (NLOAD == 0) {
 #pragma unroll
-      for (int j = a * kLoadsPerStep; j < (a + 1) * kLoadsPerStep && j < L; j++) issue_one(lkt, j);
+        for (int j = a * kLoadsPerStep; j < (a + 1) * kLoadsPerStep && j < L; j++) issue_one(lkt, j);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int a = 0; a < TN; a++) {
 #pragma unroll
       for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
-      if (NSTAGE >= 3) {
+      if (NSTAGE >= 3 && NLOAD == 0) {
 #pragma unroll
         for (int j = (TN + a) * kLoadsPerStep; j < (TN + a + 1) * kLoadsPerStep && j < L; j++) issue_one(lkt, j);
       }
@@ -506,9 +532,9 @@ int launch_gemm32(GemmParams p, hipStream_t stream, int device) {
   return launch_common<BM, BN>(c4_head_gemm32_kernel<BM, BN, WM, WN, NSTAGE>, p, 64 * WM * WN, NSTAGE * (BM + BN) * 32 * 2, stream, device);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW, int NLOAD = 0>
 int launch_gemm(GemmParams p, hipStream_t stream, int device) {
-  return launch_common<BM, BN>(c4_head_gemm_kernel<BM, BN, WM, WN, NSTAGE, MINW>, p, 64 * WM * WN, NSTAGE * (BM + BN) * BK * 2, stream, device);
+  return launch_common<BM, BN>(c4_head_gemm_kernel<BM, BN, WM, WN, NSTAGE, MINW, NLOAD>, p, 64 * (WM * WN + NLOAD), NSTAGE * (BM + BN) * BK * 2, stream, device);
 }
 
 }  // namespace
@@ -570,7 +596,9 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     // the same 128 x 192 tile on FOUR wavefronts (64 x 96 each, one per SIMD, 29 % fewer fragment bytes out of LDS):
     // slower alone (20.3 against 19.8 us at 2 048 rows) but +3.6 % games/s in the bench, same box (29.3-29.4 k against 28.3 k;
     // 128 x 48 per wavefront, config 12, the same); the F-wide layers keep the 8 wavefronts (6 / 12 there: 28.7-28.8 k).
-    config = m <= 384 ? 27 : m <= 640 ? (wide ? 9 : 27) : m <= 896 ? (wide ? 23 : 9) : m <= 1024 ? (wide ? 10 : 9) : (wide ? 6 : 11);
+    // ... and up to 1 024 rows, where a layer is a latency chain, the wave-specialised forms of round 3's small tiles (two or four
+    // wavefronts that only issue the DMA pieces: 3-15 % less time alone, tools/gemm_small_ab.sh in profiles/r04_gemm_configs.txt)
+    config = m <= 384 ? 41 : m <= 640 ? (wide ? 42 : 41) : m <= 896 ? (wide ? 44 : 42) : m <= 1024 ? (wide ? 43 : 42) : (wide ? 6 : 11);
     // The 64-channel net (K = 2 688, N = 5 376 / 2 688: four times the flops per layer): there the 256 x 192 tile
     // (64 x 96 per wavefront, 2-deep ring, 112 KB) pays -- BASELINE config 4 (2 x 2 048 rows) 862 -> 925-939 games/s,
     // config 5's per-GPU share (2 x 4 096 rows) 3 271 -> 3 671 (hipBLASLt: 911-919 / 3 736), profiles/r03_gemm_configs.txt
@@ -613,6 +641,17 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     case 32: return launch_gemm32<256, 192, 2, 4, 5>(p, st, device);   // 8 wavefronts (128 x 48), 5-deep ring
     case 33: return launch_gemm<192, 96, 2, 2, 4, 1>(p, st, device);   // 4 wavefronts (96 x 48), 4-deep ring, 144 KB
     case 34: return launch_gemm<192, 192, 2, 2, 3, 1>(p, st, device);  // 4 wavefronts (96 x 96), 3-deep ring, 144 KB
+    case 35: return launch_gemm<128, 192, 2, 4, 3, 1, 4>(p, st, device);   // config 11 wave-specialised: 8 computing + 4 loading wavefronts
+    case 36: return launch_gemm<128, 192, 2, 4, 4, 1, 4>(p, st, device);   // ... 4-deep ring (160 KB)
+    case 37: return launch_gemm<128, 192, 2, 2, 3, 1, 4>(p, st, device);   // config 6 wave-specialised: 4 computing + 4 loading wavefronts
+    case 38: return launch_gemm<128, 192, 2, 4, 3, 1, 2>(p, st, device);   // 8 computing + 2 loading wavefronts
+    case 39: return launch_gemm<128, 192, 2, 4, 3, 1, 8>(p, st, device);   // 8 computing + 8 loading wavefronts
+    case 40: return launch_gemm<96, 96, 2, 2, 3, 1, 2>(p, st, device);     // config 23 wave-specialised: 4 computing + 2 loading wavefronts
+    case 41: return launch_gemm<64, 64, 2, 2, 4, 2, 2>(p, st, device);     // config 27 wave-specialised
+    case 42: return launch_gemm<64, 96, 2, 2, 4, 2, 2>(p, st, device);     // config 9 wave-specialised
+    case 43: return launch_gemm<128, 96, 2, 2, 3, 1, 2>(p, st, device);    // config 10 wave-specialised
+    case 44: return launch_gemm<96, 96, 2, 2, 3, 1, 4>(p, st, device);     // config 23 with 4 loading wavefronts
+    case 45: return launch_gemm<64, 64, 2, 2, 4, 2, 4>(p, st, device);     // config 27 with 4 loading wavefronts
     default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
   }
 }

@@ -898,8 +898,11 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
 // leave a session's per-round chain.  Default configuration only (no Dirichlet noise, no evaluation cache, no per-launch
 // timing): everything else keeps the two launches.
 // ------------------------------------------------------------------------------------------
+// (At most 144 registers: two of this kernel's wavefronts on a SIMD then take 288 of its 512, and the launch can share a
+// compute unit with a hidden-layer GEMM workgroup of the OTHER session -- 224 registers per SIMD for the 8-wavefront form,
+// 208 for the 4-wavefront form, 120 KB + 15 KB of LDS -- instead of queueing for a free one.)
 template <typename PlaneT>
-__global__ __launch_bounds__(64 * c4ho::kHeadWaves, 1) void c4_out_step_kernel(
+__global__ __launch_bounds__(64 * c4ho::kHeadWaves, 1) __attribute__((amdgpu_num_vgpr(144))) void c4_out_step_kernel(
     const uint4* __restrict__ hp, const uint4* __restrict__ hv, const uint4* __restrict__ wp, const uint4* __restrict__ wv,
     const float* __restrict__ bp, const float* __restrict__ bv, Slot* __restrict__ a_slots, uint32_t a_n_slots, uint32_t f8, uint32_t sp8, uint32_t sv8,
     Params p) {

@@ -389,8 +389,20 @@ class InferenceNet:
         if k >= 2048:   # the 64-channel net: the automatic 256 x 192 tile for the 2F-wide layer, 128 x 192 for the F-wide ones
             return 0 if n > k else 11   # (alone at 2 048 rows: 31 us against 49)
         if m <= 1728:
-            return 23
-        return 11 if n > k else 10   # (alone the 8-wavefront form of the 128 x 192 tile is the faster one for the 2F-wide layer)
+            return 44   # 96 x 96, four computing + four loading wavefronts (round 3: config 23, the same tile without loaders)
+        # alone, the wave-specialised forms: 128 x 192 on 8 + 4 wavefronts for the 2F-wide layer, 128 x 96 on 4 + 2 for the F-wide ones
+        return 35 if n > k else 43
+
+    use_loader_waves = True   # False: round 3's tile table without the wave-specialised forms (A/B)
+
+    def _pick_config(self, m: int, n: int, k: int) -> int:
+        cfg = self._alone_config(m, n, k)
+        if self.use_loader_waves or k >= 2048:
+            return cfg
+        wide = n > k
+        if cfg == 0 and m <= 1024:      # c4_linear_bf16's automatic choice of round 3
+            return 27 if m <= 384 else ((9 if wide else 27) if m <= 640 else ((23 if wide else 9) if m <= 896 else (10 if wide else 9)))
+        return {44: 23, 35: 11, 43: 10}.get(cfg, cfg)
 
     def _linear_relu(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ReLU(x W^T + b): the hand-written MFMA GEMM, or (gemm="hipblaslt") the library's with the bias
@@ -404,7 +416,7 @@ class InferenceNet:
             y = out if out is not None else torch.empty((m, n), dtype=torch.bfloat16, device=self.device)
             check(self._L.c4_linear_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(self._bias32[b.data_ptr()].data_ptr()),
                                          C.c_void_p(y.data_ptr()), m, n, k, x.stride(0), y.stride(0), 1,
-                                         self.gemm_config[0 if n > k else 1] or self._alone_config(m, n, k),
+                                         self.gemm_config[0 if n > k else 1] or self._pick_config(m, n, k),
                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             return y
         if self.fused_epilogue:

@@ -309,8 +309,8 @@ def test_to_records_round_trip():
 
 def test_tile_choice_of_a_session_alone_on_the_device():
     """InferenceNet._alone_config (host logic, no GPU): only a session that has the device to itself asks for the
-    small tiles, only between 1 025 and 1 728 rows for both layer widths; beyond, the F-wide layers keep the 128 x 96 tile
-    and the 2F-wide layer the 8-wavefront form of the 128 x 192 tile (the automatic choice there, config 6 on four
+    small tiles, only between 1 025 and 1 728 rows for both layer widths (96 x 96, wave-specialised); beyond, the wave-specialised
+    128 x 96 tile for the F-wide layers and 128 x 192 tile for the 2F-wide layer (the automatic choice there, config 6 on four
     wavefronts, is the one that wins beside a second session); otherwise the automatic choice (0) stands."""
     from c4a0_amd.nn import InferenceNet
 
@@ -319,8 +319,8 @@ def test_tile_choice_of_a_session_alone_on_the_device():
     assert [net._alone_config(m, 2688, 1344) for m in (1, 1024, 1025, 1700, 4096)] == [0] * 5
     net.latency_mode = True
     assert net._alone_config(1024, 2688, 1344) == 0 and net._alone_config(1024, 1344, 1344) == 0
-    assert net._alone_config(1025, 2688, 1344) == 23 and net._alone_config(1728, 1344, 1344) == 23
-    assert net._alone_config(1729, 2688, 1344) == 11 and net._alone_config(1729, 1344, 1344) == 10
+    assert net._alone_config(1025, 2688, 1344) == 44 and net._alone_config(1728, 1344, 1344) == 44
+    assert net._alone_config(1729, 2688, 1344) == 35 and net._alone_config(1729, 1344, 1344) == 43
     # the 64-channel net (k = 2 688): the automatic choice for the 2F-wide layer, the 128 x 192 tile for the F-wide ones
     assert net._alone_config(4096, 2688, 2688) == 11 and net._alone_config(1500, 2688, 2688) == 11
     assert net._alone_config(4096, 5376, 2688) == 0 and net._alone_config(1500, 5376, 2688) == 0
