@@ -70,6 +70,16 @@ struct Geo {
   static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 };
 
+#ifdef C4_PHASE_STAMPS
+// Diagnostic build only (tools/tower_phases.py): where a tower workgroup's time goes.  Stamps (100 MHz device clock, first
+// wavefront of every workgroup): 0 entry, 1 input staged (images zeroed, planes in), 2 conv0 done, 2 + i residual layer i done
+// (barrier passed; the last layer: its stores acknowledged); summed over workgroups, plus the earliest entry and latest exit.
+__device__ unsigned long long c4_tower_clk[32];   // [0] workgroups, [1..24] phase ticks, [30] min entry, [31] max exit
+#define C4_TSTAMP(i) do { if (threadIdx.x == 0) tw_ts[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define C4_TSTAMP(i) do { } while (0)
+#endif
+
 struct TowerParams {
   const uint16_t* planes;   // [G][2][42] bf16
   const bf16x8* w0;         // conv0 fragments  [3 steps][MT][64 lanes]
@@ -362,6 +372,18 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
                                                              const float* __restrict__ a_bias, uint16_t* __restrict__ a_out, uint32_t a_n_boards, uint32_t a_n_blocks) {
   // flat scalar arguments (12 dwords): preloaded into SGPRs at wavefront launch (build.py: -amdgpu-kernarg-preload-count)
   const TowerParams p{a_planes, a_w0, a_w, a_bias, a_out, a_n_boards, a_n_blocks};
+#ifdef C4_PHASE_STAMPS
+  unsigned long long tw_ts[24];
+  auto tw_flush = [&](int last) {
+    if (threadIdx.x == 0) {
+      atomicAdd(&c4_tower_clk[0], 1ull);
+      for (int i = 0; i < last; i++) atomicAdd(&c4_tower_clk[1 + i], tw_ts[i + 1] - tw_ts[i]);
+      atomicMin(&c4_tower_clk[30], tw_ts[0]);
+      atomicMax(&c4_tower_clk[31], tw_ts[last]);
+    }
+  };
+#endif
+  C4_TSTAMP(0);
   using G = Geo<C, NB>;
   constexpr int MTW = G::MT / MS;
   static_assert(G::MT % MS == 0 && (!G::kStageW || MS == 1), "co-tile split");
@@ -431,6 +453,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
     if (i < NB * 42) T[b * kBS + cell_slot(cell / 7, cell % 7)] = make_uint4(in_v[j], 0, 0, 0);
   }
   __syncthreads();
+  C4_TSTAMP(1);
 
   // tiles of this wave: a contiguous range
   constexpr int kWaves = NT / 64 / MS;             // wavefronts (or MS-groups of them) that share out the cell tiles
@@ -483,6 +506,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
   });
   if (G::kStageW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's share of the staged layer has landed
   __syncthreads();
+  C4_TSTAMP(2);
   for (int layer = 1; layer <= n_layers; layer++) {
     const bool is_second = (layer & 1) == 0;         // second conv of a block: T -> X, += residual
     if (G::kStageW) {
@@ -497,12 +521,19 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
     if (kFuseOut && layer == n_layers) {   // the final layer (always the second conv of a block) stores the tower's output itself
       tower_layer<C, NB, false, true, true, kTilesPerWave, MTW, kPrefetch>(T, X, wf, p.bias + (size_t)layer * C, tile_lo, m0, lane, next_weights,
                                                                           p.out, board0, p.n_boards);
+#ifdef C4_PHASE_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (layer < 20) { C4_TSTAMP(2 + layer); tw_flush(2 + layer); }
+#endif
       return;
     }
     if (is_second) tower_layer<C, NB, false, true, false, kTilesPerWave, MTW, kPrefetch>(T, X, wf, p.bias + (size_t)layer * C, tile_lo, m0, lane, next_weights);
     else tower_layer<C, NB, false, false, false, kTilesPerWave, MTW, kPrefetch>(X, T, wf, p.bias + (size_t)layer * C, tile_lo, m0, lane, next_weights);
     if (G::kStageW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef C4_PHASE_STAMPS
+    if (layer < 20) C4_TSTAMP(2 + layer);
+#endif
   }
   }
 
@@ -533,6 +564,20 @@ int launch_tower(const TowerParams& p, uint32_t n_boards, hipStream_t stream, in
 }
 
 }  // namespace
+
+#ifdef C4_PHASE_STAMPS
+// diagnostic build only: mean time per phase (us) of the 32-channel tower's workgroups since the last reset and the span from the
+// earliest entry to the latest exit (one launch)
+extern "C" int c4_debug_tower_phases(double* phase_us, int n, double* span_us, unsigned long long* n_workgroups, int reset) {
+  unsigned long long h[32];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(c4_tower_clk), sizeof h) != hipSuccess) return C4_ERR_HIP;
+  for (int i = 0; i < n && i < 24; i++) phase_us[i] = h[0] ? (double)h[1 + i] / (double)h[0] * 0.01 : 0.0;
+  if (span_us) *span_us = h[31] > h[30] ? (double)(h[31] - h[30]) * 0.01 : 0.0;
+  if (n_workgroups) *n_workgroups = h[0];
+  if (reset) { unsigned long long z[32] = {0}; z[30] = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(c4_tower_clk), z, sizeof z) != hipSuccess) return C4_ERR_HIP; }
+  return C4_OK;
+}
+#endif
 
 extern "C" {
 

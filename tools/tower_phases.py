@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Where a workgroup of the 32-channel tower spends its time (diagnostic build: python c4a0_amd/csrc/build.py --diag).
+    python tools/tower_phases.py [boards=2048] [blocks=4] [tower_config=0]"""
+import ctypes as C, os, sys
+os.environ.setdefault("C4A0_HIP_LIB", "libc4a0_hip_diag.so")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from c4a0_amd import _lib
+from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+cfg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+dev = torch.device("cuda:0")
+L = _lib.lib()
+L.c4_debug_tower_phases.restype = C.c_int
+L.c4_debug_tower_phases.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+torch.manual_seed(0)
+net = InferenceNet(ConnectFourNet(ModelConfig(blocks, 32, 4, 2)), dev, tower_config=cfg)
+x = (torch.rand(n, 2, 6, 7, device=dev) > 0.7).to(torch.bfloat16)
+def read():
+    ph, span, nw = (C.c_double * 24)(), C.c_double(), C.c_uint64()
+    _lib.check(L.c4_debug_tower_phases(ph, 24, C.byref(span), C.byref(nw), 1))
+    return list(ph), span.value, nw.value
+for _ in range(20):
+    net.tower(x)
+read()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(200):
+    net.tower(x)
+b.record(); torch.cuda.synchronize()
+ph, _, nw = read()
+names = ["entry->input staged", "conv0"] + [f"layer {i}" for i in range(1, 2 * blocks + 1)]
+print(f"tower 32 ch, {blocks} blocks, {n} boards: {a.elapsed_time(b) / 200 * 1e3:.1f} us per launch (eager, back to back), {nw} workgroups")
+print("  mean workgroup, us: " + "  ".join(f"{nm} {v:.2f}" for nm, v in zip(names, ph)) + f"  | sum {sum(ph[:len(names)]):.2f}")
+spans = []
+for _ in range(20):
+    torch.cuda.synchronize(); net.tower(x); spans.append(read()[1])
+spans.sort()
+print(f"  in-kernel span of one launch: median {spans[10]:.2f} us, min {spans[0]:.2f}")
