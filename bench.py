@@ -80,7 +80,7 @@ def cpu_baseline(net, device, n_iter: int, threads: int, budget_s: float = 20.0)
     NN thread (NNThread::loop_until_close: drain the queue, batch the unique leaves, call the
     evaluator), `threads - 1` C worker threads are the MctsThreads, games travel over two queues, so
     network evaluation and tree work overlap (oracle c4o_self_play_async).  The evaluator is the SAME
-    bf16 network on the GPU through the numpy callback round trip of nn.py:119-130.
+    bf16 network on the GPU through the numpy callback round trip of nn.py:119-130 (InferenceNet.forward_numpy).
 
     Reported as the MEDIAN of >= 3 equal samples of the same workload (with min / max / n): a probe
     sizes the sample so that the three together take about `budget_s` seconds.  The NN thread keeps
@@ -91,12 +91,9 @@ def cpu_baseline(net, device, n_iter: int, threads: int, budget_s: float = 20.0)
 
     cb_time = [0.0]
 
-    def cb(_model_id, x):
+    def cb(_model_id, x):   # the reference caller's callback (training.py:179-189): model.forward_numpy(x)
         t = time.perf_counter()
-        with torch.no_grad():
-            lp, q = net(torch.from_numpy(x).to(device))
-            lp, q = lp.float().cpu().numpy(), q.float().cpu().numpy()
-        out = np.ascontiguousarray(lp), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
+        out = net.forward_numpy(x)
         cb_time[0] += time.perf_counter() - t
         return out
 
