@@ -70,9 +70,47 @@ def callback_job():
     n_games_total += n_games
 
 
+_nets = {}
+n_fused_jobs = 0
+
+
+def fused_job():
+    """The bf16 network in device mode: play_games (HIP graphs; the output layers inside the step's launch,
+    c4_session_step_head_out; two sessions from 2 048 slots) against an eager DeviceSession.run (stand-alone output kernel and
+    step kernel, per-launch timing on) -- byte-identical records for random widths incl. non-multiples of 16 and refills."""
+    global n_jobs, n_games_total, n_fused_jobs
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+    from c4a0_amd.results import GameMetadata, results_from_records
+    heads = rng.choice([(2, 2), (4, 2), (1, 1), (3, 1)])
+    if heads not in _nets:
+        torch.manual_seed(hash(heads) & 0xFFFF)
+        _nets[heads] = InferenceNet(ConnectFourNet(ModelConfig(rng.choice([1, 2]), 32, *heads)), torch.device("cuda:0"), dtype=torch.bfloat16)
+    net = _nets[heads]
+    n_games = rng.choice([1, 5, 16, 17, 40, 130])
+    n_slots = rng.choice([1, 7, 8, 15, 16, 17, 31, 33, 100])
+    n_iter = rng.choice([2, 5, 12, 30])
+    reqs = [(5000 + 3 * i, 0, 0) for i in range(n_games)]
+    cfg = dict(fused=True, heads=heads, n_games=n_games, n_slots=n_slots, n_iter=n_iter)
+    got = c4a0_amd.play_games([c4a0_amd.GameMetadata(*r) for r in reqs], 64, n_iter, 6.6, 0.01, evaluator=net, resident_games=n_slots,
+                              concurrent_sessions=rng.choice([1, 1, 2]))
+    s = DeviceSession(min(n_slots, n_games), n_iter, 6.6, 0.01, planes_dtype=torch.bfloat16)
+    s.set_games(reqs)
+    s.run(net)                                   # eager: evaluate() + step(), the two stand-alone kernels
+    want = results_from_records([GameMetadata(*r) for r in reqs], s.drain_samples(), s.sample_counts())
+    s.close()
+    assert got.to_records()[0].tobytes() == want.to_records()[0].tobytes(), cfg
+    n_jobs += 1
+    n_fused_jobs += 1
+    n_games_total += n_games
+
+
 while time.time() - t0 < budget:
-    if rng.random() < 0.3:
+    r = rng.random()
+    if r < 0.25:
         callback_job()
+        continue
+    if r < 0.45:
+        fused_job()
         continue
     n_games = rng.choice([1, 2, 3, 7, 8, 9, 17, 40, 100])
     n_slots = rng.choice([1, 2, 7, 8, 9, 16, 33])
@@ -117,5 +155,5 @@ while time.time() - t0 < budget:
     assert got == oracle_samples_by_game(want), cfg
     n_jobs += 1
     n_games_total += len(ids)
-print(f"fuzz parity ok: {n_jobs} jobs ({n_cb_jobs} of them through the numpy callback, one or several models), {n_games_total} games in {time.time() - t0:.0f} s; "
+print(f"fuzz parity ok: {n_jobs} jobs ({n_cb_jobs} of them through the numpy callback, one or several models; {n_fused_jobs} with the bf16 network, fused graph path vs eager), {n_games_total} games in {time.time() - t0:.0f} s; "
       f"{n_errs} more jobs ended in the same panic on both sides")
