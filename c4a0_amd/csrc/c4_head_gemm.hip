@@ -124,15 +124,23 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // bytes per row segment.  Values are untouched (a permutation of registers): same bits as the 8-byte form.
 // (Write-through `sc1` stores, so that the launch leaves no dirty lines for its end-of-kernel write-back, measured
 // 2.4 % SLOWER in the bench, same box: plain stores stay.)
-template <int TM, int TN>
-__device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[TN][TM], const f32x4 (&bias_v)[TN], const GemmParams& p, int m_wave0, int n_wave0,
-                                                int li, int lg) {
-  const bool relu = p.relu != 0;
+// max(v, 0) as ONE instruction.  fmaxf(v, 0.f) compiles to two (hipcc first canonicalises v with v_max v, v, v: sixteen instead of
+// eight VALU instructions per stored tile pair in the epilogue, which is issue-bound); v_max_f32 in IEEE mode already is maxNum:
+// the same result for every v, NaN -> 0 included.
+__device__ __forceinline__ float relu1(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
+template <int TM, int TN, bool RELU>
+__device__ __forceinline__ void store_wave_tile_impl(const f32x4 (&acc)[TN][TM], const f32x4 (&bias_v)[TN], const GemmParams& p, int m_wave0, int n_wave0,
+                                                     int li, int lg) {
   auto finish = [&](const f32x4& a, const f32x4& bv) __attribute__((always_inline)) {
     f32x4 v = a + bv;
-    if (relu) {
+    if (RELU) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+      for (int r = 0; r < 4; r++) v[r] = relu1(v[r]);
     }
     return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4));
   };
@@ -148,9 +156,7 @@ __device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[TN][TM], cons
       const auto sx = __builtin_amdgcn_permlane16_swap(o0.x, o1.x, false, false);
       const auto sy = __builtin_amdgcn_permlane16_swap(o0.y, o1.y, false, false);
       const u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
-      if (m16 + 32 * pb < (int)p.M) {
-        *reinterpret_cast<u32x4*>(y16 + a * 16) = v;
-      }
+      if (m16 + 32 * pb < (int)p.M) *reinterpret_cast<u32x4*>(y16 + a * 16) = v;
     }
     y16 += pair_step;
   }
@@ -162,6 +168,13 @@ __device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[TN][TM], cons
       for (int a = 0; a < TN; a++) *reinterpret_cast<uint2*>(y8 + a * 16) = finish(acc[a][TM - 1], bias_v[a]);
     }
   }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[TN][TM], const f32x4 (&bias_v)[TN], const GemmParams& p, int m_wave0, int n_wave0,
+                                                int li, int lg) {
+  if (p.relu) store_wave_tile_impl<TM, TN, true>(acc, bias_v, p, m_wave0, n_wave0, li, lg);   // one uniform branch, not one per tile
+  else store_wave_tile_impl<TM, TN, false>(acc, bias_v, p, m_wave0, n_wave0, li, lg);
 }
 
 // NLOAD = 0: every wavefront computes AND issues its share of the DMA pieces (interleaved with its MFMAs).
