@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <type_traits>
 
 #include "../../include/c4a0_hip.h"
 #include "c4_host.hpp"
@@ -184,7 +185,11 @@ __device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[TN][TM], cons
 // wavefront is held 60-185 cycles per piece; in the NLOAD = 0 form those cycles come out of the wavefronts that should be
 // issuing MFMAs (768 cycles of matrix work per k-tile and SIMD take 1 270-1 320).  Same LDS image, same fragment reads, same
 // MFMA order: same bits.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW, int NLOAD = 0>
+// STAG = 1 (8 computing wavefronts, NLOAD = 0): wavefronts 4-7 -- the partners of wavefronts 0-3 on their SIMDs -- run half a k-tile
+// behind: the second half's MFMAs of a k-tile are deferred past the next barrier (their fragments are in registers), so that
+// right after a barrier one wavefront of every SIMD multiplies while its partner waits for its fragment reads.  Every
+// accumulator still sees its MFMAs in the same order: same bits.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW, int NLOAD = 0, int STAG = 0>
 __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_kernel(C4_GEMM_ARGS) {
   C4_GEMM_UNPACK();
   constexpr int kWaves = WM * WN;                             // computing wavefronts
@@ -296,7 +301,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
 
   C4_GSTAMP(1);
   C4_CLK_BEGIN();
-  for (int kt = 0; kt < KT; kt++) {
+  static_assert(!STAG || (NLOAD == 0 && WM * WN == 8 && NSTAGE >= 3), "the stagger is written for 8 computing wavefronts that issue their own pieces");
+  bf16x8 afr[2][TN], bfr[2][TM];
+  // One k-tile.  kLate: a wavefront that runs half a k-tile behind (STAG).
+  auto body = [&](int kt, auto late_c) __attribute__((always_inline)) {
+    constexpr bool kLate = decltype(late_c)::value;
     // k-tile kt must have landed; the NSTAGE - 2 younger ones stay in flight (the same count in every iteration:
     // see issue_one for the pieces past the last k-tile)
     if (NLOAD == 0) wait_vmcnt<(NSTAGE - 2) * L>();
@@ -317,12 +326,17 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
     // MFMAs need all TM of them and one weight fragment); the second half's reads are issued between
     // the first half's MFMAs, so that at most ~14 LDS reads are outstanding (the counter holds 15)
     // and the MFMAs of a half never wait for more than the fragments they use.
-    bf16x8 afr[2][TN], bfr[2][TM];
     auto rd_x = [&](int kk, int b) __attribute__((always_inline)) {
       bfr[kk][b] = *reinterpret_cast<const bf16x8*>(st + x_base + (kk ? frag_off1 : frag_off0) + b * 2048);
     };
     auto rd_w = [&](int kk, int a) __attribute__((always_inline)) {
       afr[kk][a] = *reinterpret_cast<const bf16x8*>(st + w_base + (kk ? frag_off1 : frag_off0) + a * 2048);
+    };
+    auto issue_step = [&](int step) __attribute__((always_inline)) {   // the DMA pieces handed out behind MFMA group `step` of 2 TN
+      if (NLOAD == 0 && (NSTAGE >= 3 || step < TN)) {
+#pragma unroll
+        for (int j = step * kLoadsPerStep; j < (step + 1) * kLoadsPerStep && j < L; j++) issue_one(lkt, j);
+      }
     };
 #pragma unroll
     for (int b = 0; b < TM; b++) rd_x(0, b);
@@ -330,6 +344,18 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
     for (int a = 0; a < TN; a++) rd_w(0, a);
     __builtin_amdgcn_sched_barrier(0);
     constexpr int kPerStep = (TN + TM + TN - 1) / TN;           // second-half reads issued behind each weight row's MFMAs
+    if (kLate) {
+      // the deferred second half of k-tile kt - 1 (fragments in afr[1] / bfr[1]) runs while the reads above travel
+#pragma unroll
+      for (int a = 0; a < TN; a++) {
+        if (kt > 0) {
+#pragma unroll
+          for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
+        }
+        issue_step(a);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
 #pragma unroll
     for (int a = 0; a < TN; a++) {
 #pragma unroll
@@ -338,22 +364,30 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
       for (int r = a * kPerStep; r < (a + 1) * kPerStep && r < TN + TM; r++) {
         if (r < TM) rd_x(1, r); else rd_w(1, r - TM);
       }
-      if (NLOAD == 0) {
-#pragma unroll
-        for (int j = a * kLoadsPerStep; j < (a + 1) * kLoadsPerStep && j < L; j++) issue_one(lkt, j);
-      }
+      issue_step(kLate ? TN + a : a);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (kLate) {
+      // the second half's fragments must be in registers before the next barrier lets a DMA piece into this stage
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
 #pragma unroll
-    for (int a = 0; a < TN; a++) {
+      for (int a = 0; a < TN; a++) {
+#pragma unroll
+        for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
+        issue_step(TN + a);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  if (STAG && wave >= kWaves / 2) {
+    for (int kt = 0; kt < KT; kt++) body(kt, std::true_type{});
+#pragma unroll
+    for (int a = 0; a < TN; a++)                                // the last k-tile's deferred half
 #pragma unroll
       for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
-      if (NSTAGE >= 3 && NLOAD == 0) {
-#pragma unroll
-        for (int j = (TN + a) * kLoadsPerStep; j < (TN + a + 1) * kLoadsPerStep && j < L; j++) issue_one(lkt, j);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+  } else {
+    for (int kt = 0; kt < KT; kt++) body(kt, std::false_type{});
   }
 
   C4_CLK_END();
@@ -545,9 +579,9 @@ int launch_gemm32(GemmParams p, hipStream_t stream, int device) {
   return launch_common<BM, BN>(c4_head_gemm32_kernel<BM, BN, WM, WN, NSTAGE>, p, 64 * WM * WN, NSTAGE * (BM + BN) * 32 * 2, stream, device);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW, int NLOAD = 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW, int NLOAD = 0, int STAG = 0>
 int launch_gemm(GemmParams p, hipStream_t stream, int device) {
-  return launch_common<BM, BN>(c4_head_gemm_kernel<BM, BN, WM, WN, NSTAGE, MINW, NLOAD>, p, 64 * (WM * WN + NLOAD), NSTAGE * (BM + BN) * BK * 2, stream, device);
+  return launch_common<BM, BN>(c4_head_gemm_kernel<BM, BN, WM, WN, NSTAGE, MINW, NLOAD, STAG>, p, 64 * (WM * WN + NLOAD), NSTAGE * (BM + BN) * BK * 2, stream, device);
 }
 
 }  // namespace
@@ -665,6 +699,8 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     case 43: return launch_gemm<128, 96, 2, 2, 3, 1, 2>(p, st, device);    // config 10 wave-specialised
     case 44: return launch_gemm<96, 96, 2, 2, 3, 1, 4>(p, st, device);     // config 23 with 4 loading wavefronts
     case 45: return launch_gemm<64, 64, 2, 2, 4, 2, 4>(p, st, device);     // config 27 with 4 loading wavefronts
+    case 46: return launch_gemm<128, 192, 2, 4, 3, 1, 0, 1>(p, st, device); // config 11 with wavefronts 4-7 half a k-tile behind
+    case 47: return launch_gemm<128, 192, 2, 4, 4, 1, 0, 1>(p, st, device); // ... 4-deep ring
     default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
   }
 }
