@@ -713,6 +713,51 @@ __global__ __launch_bounds__(64 * kHeadWaves, 1) void c4_head_out_mfma_kernel(
 
 }  // namespace
 
+namespace {
+// float32 -> bf16, round to nearest even (what torch's .to(bfloat16) does; NaN -> the quiet NaN 0x7FC0)
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+  const uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// 8 values per thread: two 16-byte reads (over PCIe when the batch lives in pinned host memory), one 16-byte store;
+// boards past the batch's own count (a captured launch covers a whole bucket of rows) become empty boards
+__global__ __launch_bounds__(256) void c4_planes_from_f32_kernel(const c4_f32_batch* __restrict__ slot, const float* __restrict__ src,
+                                                                 uint32_t n_valid, uint4* __restrict__ dst, uint32_t n8) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  if (slot) { src = slot->data; n_valid = slot->n_boards; }
+  uint4 o = make_uint4(0, 0, 0, 0);
+  if (8 * (size_t)i < 84 * (size_t)n_valid) {     // 84 values per board: an odd board count ends inside a thread's eight
+    const float4* s = reinterpret_cast<const float4*>(src) + 2 * (size_t)i;
+    float4 a = s[0], b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (8 * (size_t)i + 4 < 84 * (size_t)n_valid) b = s[1];
+    o.x = bf16_rne(a.x) | (bf16_rne(a.y) << 16);
+    o.y = bf16_rne(a.z) | (bf16_rne(a.w) << 16);
+    o.z = bf16_rne(b.x) | (bf16_rne(b.y) << 16);
+    o.w = bf16_rne(b.z) | (bf16_rne(b.w) << 16);
+  }
+  dst[i] = o;
+}
+}  // namespace
+
+extern "C" int c4_planes_from_f32(const c4_f32_batch* batch_slot, const float* src, uint32_t n_boards, void* planes_dev, uint32_t n_rows_out,
+                                  void* stream) {
+  if ((!batch_slot && !src && n_boards) || !planes_dev) return c4host::fail(C4_ERR_BAD_ARG, "c4_planes_from_f32: null argument");
+  if (((uintptr_t)src | (uintptr_t)planes_dev | (uintptr_t)batch_slot) & 15) return c4host::fail(C4_ERR_BAD_ARG, "c4_planes_from_f32: arrays must be 16-byte aligned");
+  if (n_rows_out % 2) return c4host::fail(C4_ERR_BAD_ARG, "c4_planes_from_f32: n_rows_out must be even (84 values per board, 8 per thread)");
+  if (!batch_slot && n_boards > n_rows_out) return c4host::fail(C4_ERR_BAD_ARG, "c4_planes_from_f32: n_boards > n_rows_out");
+  if (n_rows_out == 0) return C4_OK;
+  const int device = c4host::stream_device((hipStream_t)stream);
+  c4host::DeviceGuard guard(device);
+  if (guard.error() != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_planes_from_f32: hipSetDevice: ") + hipGetErrorString(guard.error()));
+  const uint32_t n8 = n_rows_out / 2 * 21;     // 84 n / 8
+  c4_planes_from_f32_kernel<<<dim3((n8 + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(batch_slot, src, n_boards, (uint4*)planes_dev, n8);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_planes_from_f32 launch: ") + hipGetErrorString(e));
+  return C4_OK;
+}
+
 extern "C" int c4_head_out_bf16(const void* hidden_policy_dev, const void* hidden_value_dev, const void* w_policy_dev,
                                 const void* w_value_dev, const float* b_policy_dev, const float* b_value_dev,
                                 uint32_t n_boards, uint32_t features, uint32_t policy_row_stride, uint32_t value_row_stride,

@@ -27,7 +27,7 @@ extern "C" {
  * middle of c4_conv_tower_bf16's arguments, version 5 c4_session_step_head_out).  A consumer compiled against this header checks it once at start-up --
  * `if (c4_abi_version() != C4_ABI_VERSION) refuse` -- because the dynamic linker compares names, not signatures
  * (tests/abi_consumer*.c and c4a0_amd/_lib.py do).  No reference counterpart: the reference's boundary is PyO3. */
-#define C4_ABI_VERSION 5
+#define C4_ABI_VERSION 6
 
 #define C4_N_COLS 7          /* rust/src/c4r.rs:45, lib.rs:28 */
 #define C4_N_ROWS 6          /* rust/src/c4r.rs:44, lib.rs:29 */
@@ -312,6 +312,21 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
  * below 2 GiB.  config 0 = automatic, 1..47 = a specific tile configuration (tools/gemm_probe.py; all compute the same bits). */
 int c4_linear_bf16(const void* x_dev, const void* w_dev, const float* bias_dev, void* y_dev, uint32_t m, uint32_t n,
                    uint32_t k, uint32_t ldx, uint32_t ldy, uint32_t relu, uint32_t config, void* stream);
+
+/* The entry of `forward_numpy` (nn.py:119-130: `torch.from_numpy(x).to(device)` under autocast): float32 positions
+ * [n_boards][2][6][7] -> the tower's bf16 planes [n_rows_out][2][6][7] (round to nearest even; rows n_boards .. n_rows_out - 1
+ * become empty boards, so that a launch sized for a bucket of rows serves any smaller batch).  The batch may live in device
+ * memory or in PINNED host memory (then the kernel reads it over PCIe: no staging copy).  batch_slot != NULL: the kernel
+ * takes the batch's address AND its board count from *batch_slot (pinned host or device memory) instead of `src` /
+ * `n_boards`, so that a captured launch (one HIP-graph replay per call) serves a different array every call.  The slot's
+ * n_boards <= n_rows_out is the caller's to keep.  n_rows_out even; arrays and the slot 16-byte aligned. */
+typedef struct c4_f32_batch {
+  const float* data;
+  uint32_t n_boards;
+  uint32_t reserved;
+} c4_f32_batch;
+int c4_planes_from_f32(const c4_f32_batch* batch_slot, const float* src, uint32_t n_boards, void* planes_dev, uint32_t n_rows_out,
+                       void* stream);
 
 /* Output layers of both heads in one launch (nn.py:84-85,98-99): policy Linear(F->7) + LogSoftmax
  * and value Linear(F->2) + Tanh.  hidden_*_dev bf16 [n_boards][features] with row strides
