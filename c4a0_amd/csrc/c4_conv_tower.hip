@@ -34,6 +34,7 @@
 #include "../../include/c4a0_hip.h"
 #include "c4_head_out.hpp"
 #include "c4_host.hpp"
+#include "c4_timeline.hpp"
 
 namespace {
 
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
                                                              const float* __restrict__ a_bias, uint16_t* __restrict__ a_out, uint32_t a_n_boards, uint32_t a_n_blocks) {
   // flat scalar arguments (12 dwords): preloaded into SGPRs at wavefront launch (build.py: -amdgpu-kernarg-preload-count)
   const TowerParams p{a_planes, a_w0, a_w, a_bias, a_out, a_n_boards, a_n_blocks};
+  C4_TL_BEGIN();
 #ifdef C4_PHASE_STAMPS
   unsigned long long tw_ts[24];
   auto tw_flush = [&](int last) {
@@ -525,6 +527,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (layer < 20) { C4_TSTAMP(2 + layer); tw_flush(2 + layer); }
 #endif
+      C4_TL_END(1, p.out);
       return;
     }
     if (is_second) tower_layer<C, NB, false, true, false, kTilesPerWave, MTW, kPrefetch>(T, X, wf, p.bias + (size_t)layer * C, tile_lo, m0, lane, next_weights);
@@ -549,6 +552,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
       reinterpret_cast<uint4*>(p.out)[((size_t)g * 42 + cell) * G::KG + kg] = v;
     }
   }
+  C4_TL_END(1, p.out);
 }
 
 template <int C, int NB, int NT, int MS, bool ST = false>
@@ -578,6 +582,8 @@ extern "C" int c4_debug_tower_phases(double* phase_us, int n, double* span_us, u
   return C4_OK;
 }
 #endif
+
+C4_TL_SETTER(c4_debug_timeline_tower)
 
 extern "C" {
 

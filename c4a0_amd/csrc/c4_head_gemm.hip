@@ -32,6 +32,7 @@
 
 #include "../../include/c4a0_hip.h"
 #include "c4_host.hpp"
+#include "c4_timeline.hpp"
 
 namespace {
 
@@ -189,7 +190,11 @@ __device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[TN][TM], cons
 // behind: the second half's MFMAs of a k-tile are deferred past the next barrier (their fragments are in registers), so that
 // right after a barrier one wavefront of every SIMD multiplies while its partner waits for its fragment reads.  Every
 // accumulator still sees its MFMAs in the same order: same bits.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW, int NLOAD = 0, int STAG = 0>
+// WST = 2 (with NSTAGE = 3): a SPLIT ring -- three stages of the X operand, two of the W operand -- for the 256 x 192 tile, whose
+// three full stages (168 KB) do not fit a CU's 160 KB: 3 x 32 + 2 x 24 = 144 KB.  Per k-tile a wavefront issues the W pieces of
+// k-tile kt + 1 FIRST (they have the rest of this k-tile to land), then the X pieces of k-tile kt + 2.  Same LDS image per
+// stage, same fragment reads, same MFMA order: same bits.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW, int NLOAD = 0, int STAG = 0, int WST = 0>
 __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_kernel(C4_GEMM_ARGS) {
   C4_GEMM_UNPACK();
   constexpr int kWaves = WM * WN;                             // computing wavefronts
@@ -201,9 +206,15 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
   static_assert(kChunks % kIssuers == 0, "every issuing wavefront issues the same number of loads per k-tile (counted waits)");
   static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "wave tiles are multiples of 16");
   static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+  constexpr bool kSplit = WST != 0;
+  constexpr int kXStage = BM * BK * 2, kWStage = BN * BK * 2;
+  constexpr int LX = (BM / 8) / kIssuers, LW = L - LX;        // split ring: a wavefront's pieces i < LX are X rows, the others W rows
+  static_assert(!kSplit || (NLOAD == 0 && STAG == 0 && NSTAGE == 3 && WST == 2 && (BM / 8) % kIssuers == 0 && (BN / 8) % kIssuers == 0),
+                "the split ring is written for three X stages + two W stages, every wavefront issuing whole shares of both");
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
   C4_CLK_DECL();
   C4_GSTAMP(0);
+  C4_TL_BEGIN();
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -255,10 +266,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
   // for them in front of the epilogue, and for the last row of a column view bytes beyond the allocation)
   const int KT = (int)p.K / BK;
   auto issue_one = [&](int kt, int i) __attribute__((always_inline)) {
-    uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
     const int c = (issuer < 0 ? 0 : issuer) + kIssuers * i;
+    uint8_t* dst = lds + (kt % NSTAGE) * kStageBytes + c * 1024;
+    if (kSplit) dst = c < BM / 8 ? lds + (kt % NSTAGE) * kXStage + c * 1024 : lds + NSTAGE * kXStage + (kt % (kSplit ? WST : 1)) * kWStage + (c - BM / 8) * 1024;
     const uint32_t tail = kt >= KT ? 0x80000000u : 0u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds((c < BM / 8) ? x_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)(st + c * 1024), 16,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((c < BM / 8) ? x_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)dst, 16,
                                              (int)(src_off[i] | tail), kt * (BK * 2), 0, 0);
   };
   auto issue = [&](int kt) __attribute__((always_inline)) {
@@ -288,15 +300,23 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
   const uint32_t frag_off0 = (uint32_t)li * 128u + (uint32_t)(((0 + lg) ^ (li & 7)) * 16);
   const uint32_t frag_off1 = (uint32_t)li * 128u + (uint32_t)(((4 + lg) ^ (li & 7)) * 16);
   const uint32_t x_base = (uint32_t)(wm * (BM / WM)) * 128u;
-  const uint32_t w_base = (uint32_t)(BM * BK * 2) + (uint32_t)(wn * (BN / WN)) * 128u;
+  const uint32_t w_base = (uint32_t)(wn * (BN / WN)) * 128u;   // inside the stage's W part
 
   // this wavefront's biases: requested now, used after the last k-tile (the epilogue used to open with this round trip)
   f32x4 bias_v[TN];
 #pragma unroll
   for (int a = 0; a < TN; a++) bias_v[a] = *reinterpret_cast<const f32x4*>(p.bias + tn0 + wn * (BN / WN) + a * 16 + 4 * lg);
-  if (NLOAD == 0) {
+  if (NLOAD == 0 && !kSplit) {
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; s++) issue(s);
+  }
+  if (kSplit) {   // X(0), W(0), X(1): in that order, so that "all but my youngest LX pieces" covers both operands of k-tile 0
+#pragma unroll
+    for (int i = 0; i < LX; i++) issue_one(0, i);
+#pragma unroll
+    for (int i = LX; i < L; i++) issue_one(0, i);
+#pragma unroll
+    for (int i = 0; i < LX; i++) issue_one(1, i);
   }
 
   C4_GSTAMP(1);
@@ -308,7 +328,8 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
     constexpr bool kLate = decltype(late_c)::value;
     // k-tile kt must have landed; the NSTAGE - 2 younger ones stay in flight (the same count in every iteration:
     // see issue_one for the pieces past the last k-tile)
-    if (NLOAD == 0) wait_vmcnt<(NSTAGE - 2) * L>();
+    if (kSplit) wait_vmcnt<LX>();                               // (split ring: only the X pieces of k-tile kt + 1 are younger than W(kt))
+    else if (NLOAD == 0) wait_vmcnt<(NSTAGE - 2) * L>();
     __builtin_amdgcn_s_barrier();                               // everybody's pieces of kt landed; everybody left buffer (kt - 1) % NSTAGE
 #ifdef C4_GEMM_CLOCK
     if (kt == 0) C4_GSTAMP(2);
@@ -321,21 +342,26 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
     const int lkt = kt + NSTAGE - 1;
     constexpr int kLoadSteps = NSTAGE == 2 ? TN : 2 * TN;
     constexpr int kLoadsPerStep = (L + kLoadSteps - 1) / kLoadSteps;
-    const uint8_t* st = lds + (kt % NSTAGE) * kStageBytes;
+    const uint8_t* stx = kSplit ? lds + (kt % NSTAGE) * kXStage : lds + (kt % NSTAGE) * kStageBytes;
+    const uint8_t* stw = kSplit ? lds + NSTAGE * kXStage + (kt % (kSplit ? WST : 1)) * kWStage : stx + kXStage;
     // Fragment reads of the first 32-deep half are requested up front (activations first: the first
     // MFMAs need all TM of them and one weight fragment); the second half's reads are issued between
     // the first half's MFMAs, so that at most ~14 LDS reads are outstanding (the counter holds 15)
     // and the MFMAs of a half never wait for more than the fragments they use.
     auto rd_x = [&](int kk, int b) __attribute__((always_inline)) {
-      bfr[kk][b] = *reinterpret_cast<const bf16x8*>(st + x_base + (kk ? frag_off1 : frag_off0) + b * 2048);
+      bfr[kk][b] = *reinterpret_cast<const bf16x8*>(stx + x_base + (kk ? frag_off1 : frag_off0) + b * 2048);
     };
     auto rd_w = [&](int kk, int a) __attribute__((always_inline)) {
-      afr[kk][a] = *reinterpret_cast<const bf16x8*>(st + w_base + (kk ? frag_off1 : frag_off0) + a * 2048);
+      afr[kk][a] = *reinterpret_cast<const bf16x8*>(stw + w_base + (kk ? frag_off1 : frag_off0) + a * 2048);
     };
     auto issue_step = [&](int step) __attribute__((always_inline)) {   // the DMA pieces handed out behind MFMA group `step` of 2 TN
       if (NLOAD == 0 && (NSTAGE >= 3 || step < TN)) {
 #pragma unroll
-        for (int j = step * kLoadsPerStep; j < (step + 1) * kLoadsPerStep && j < L; j++) issue_one(lkt, j);
+        for (int j = step * kLoadsPerStep; j < (step + 1) * kLoadsPerStep && j < L; j++) {
+          if (!kSplit) issue_one(lkt, j);
+          else if (j < LW) issue_one(kt + WST - 1, LX + j);     // W of the next k-tile first
+          else issue_one(kt + NSTAGE - 1, j - LW);              // then X two k-tiles ahead
+        }
       }
     };
 #pragma unroll
@@ -408,6 +434,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
   C4_GSTAMP(7);
   C4_CLK_FLUSH();
 #endif
+  C4_TL_END(2, p.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -579,9 +606,10 @@ int launch_gemm32(GemmParams p, hipStream_t stream, int device) {
   return launch_common<BM, BN>(c4_head_gemm32_kernel<BM, BN, WM, WN, NSTAGE>, p, 64 * WM * WN, NSTAGE * (BM + BN) * 32 * 2, stream, device);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW, int NLOAD = 0, int STAG = 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW, int NLOAD = 0, int STAG = 0, int WST = 0>
 int launch_gemm(GemmParams p, hipStream_t stream, int device) {
-  return launch_common<BM, BN>(c4_head_gemm_kernel<BM, BN, WM, WN, NSTAGE, MINW, NLOAD, STAG>, p, 64 * (WM * WN + NLOAD), NSTAGE * (BM + BN) * BK * 2, stream, device);
+  return launch_common<BM, BN>(c4_head_gemm_kernel<BM, BN, WM, WN, NSTAGE, MINW, NLOAD, STAG, WST>, p, 64 * (WM * WN + NLOAD),
+                               WST ? (NSTAGE * BM + WST * BN) * BK * 2 : NSTAGE * (BM + BN) * BK * 2, stream, device);
 }
 
 }  // namespace
@@ -608,6 +636,8 @@ extern "C" int c4_debug_gemm_phases(double* phase_us, double* span_us, int reset
   return C4_OK;
 }
 #endif
+
+C4_TL_SETTER(c4_debug_timeline_gemm)
 
 extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float* bias_dev, void* y_dev, uint32_t m, uint32_t n,
                               uint32_t k, uint32_t ldx, uint32_t ldy, uint32_t relu, uint32_t config, void* stream) {
@@ -701,6 +731,8 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     case 45: return launch_gemm<64, 64, 2, 2, 4, 2, 4>(p, st, device);     // config 27 with 4 loading wavefronts
     case 46: return launch_gemm<128, 192, 2, 4, 3, 1, 0, 1>(p, st, device); // config 11 with wavefronts 4-7 half a k-tile behind
     case 47: return launch_gemm<128, 192, 2, 4, 4, 1, 0, 1>(p, st, device); // ... 4-deep ring
+    case 48: return launch_gemm<256, 192, 4, 2, 3, 1, 0, 0, 2>(p, st, device); // 256 x 192 on 8 wavefronts (64 x 96 each), split ring 3 X + 2 W stages = 144 KB: 112 workgroups for the 2F-wide layer at 2 048 rows
+    case 49: return launch_gemm<256, 192, 2, 2, 3, 1, 0, 0, 2>(p, st, device); // ... on 4 wavefronts (128 x 96 each)
     default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
   }
 }

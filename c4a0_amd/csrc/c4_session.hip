@@ -37,6 +37,7 @@
 #include "c4_device.hpp"
 #include "c4_head_out.hpp"
 #include "c4_host.hpp"
+#include "c4_timeline.hpp"
 
 #pragma clang fp contract(off)
 
@@ -898,15 +899,21 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
 // leave a session's per-round chain.  Default configuration only (no Dirichlet noise, no evaluation cache, no per-launch
 // timing): everything else keeps the two launches.
 // ------------------------------------------------------------------------------------------
-// (At most 144 registers: two of this kernel's wavefronts on a SIMD then take 288 of its 512, and the launch can share a
-// compute unit with a hidden-layer GEMM workgroup of the OTHER session -- 224 registers per SIMD for the 8-wavefront form,
-// 208 for the 4-wavefront form, 120 KB + 15 KB of LDS -- instead of queueing for a free one.)
+// (151 registers: two of this kernel's wavefronts on a SIMD take 304 of its 512, and the launch shares a compute unit with a
+// 4-wavefront hidden-layer GEMM workgroup of the OTHER session -- 208 registers per SIMD, 120 KB + 15 KB of LDS -- instead of
+// queueing for a free one; not with the 8-wavefront form's 2 x 112.)
+#ifdef C4_OUT_STEP_WAVES_PER_EU   // diagnostic (build_variant.py ... -DC4_OUT_STEP_WAVES_PER_EU=4): 128 registers, fits beside any GEMM workgroup; spills 116 bytes per lane
+#define C4_OUT_STEP_ATTR __attribute__((amdgpu_waves_per_eu(C4_OUT_STEP_WAVES_PER_EU, C4_OUT_STEP_WAVES_PER_EU)))
+#else
+#define C4_OUT_STEP_ATTR
+#endif
 template <typename PlaneT>
-__global__ __launch_bounds__(64 * c4ho::kHeadWaves, 1) __attribute__((amdgpu_num_vgpr(144))) void c4_out_step_kernel(
+__global__ __launch_bounds__(64 * c4ho::kHeadWaves, 1) C4_OUT_STEP_ATTR void c4_out_step_kernel(
     const uint4* __restrict__ hp, const uint4* __restrict__ hv, const uint4* __restrict__ wp, const uint4* __restrict__ wv,
     const float* __restrict__ bp, const float* __restrict__ bv, Slot* __restrict__ a_slots, uint32_t a_n_slots, uint32_t f8, uint32_t sp8, uint32_t sv8,
     Params p) {
   __shared__ c4ho::Shared sh;
+  C4_TL_BEGIN();
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7;
   const uint32_t wave_index = blockIdx.x * 2 + wave;                    // wavefronts 0 and 1: games 16 blockIdx.x + 8 wave + (lane >> 3)
   const uint32_t g = wave_index * 8 + (lane >> 3);
@@ -921,6 +928,7 @@ __global__ __launch_bounds__(64 * c4ho::kHeadWaves, 1) __attribute__((amdgpu_num
   const float nn_logit = sh.res[b][sub < 7 ? sub : 6];
   const float nn_q = sh.res[b][7 + (sub & 1)];
   step_body<PlaneT, false, false>(p, wave_index, lane, a_n_slots, st, hot, nn_logit, nn_q, 0ull);
+  C4_TL_END(3, a_slots);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1264,6 +1272,8 @@ struct c4_session {
   uint32_t* uniq_row = nullptr;
   uint32_t* uniq_count = nullptr;
 };
+
+C4_TL_SETTER(c4_debug_timeline_session)
 
 extern "C" {
 
