@@ -669,13 +669,14 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
   // CU: 18.0 / 12.2 against 19.4 / 12.5 at 1 700 rows; c4a0_amd/nn.py latency_mode).
   if (config == 0) {
     const bool wide = n > k;
-    // Round 4 (after the prologue / epilogue work, profiles/r04_gemm_configs.txt): above 1 024 rows the 2F-wide layer runs
-    // the same 128 x 192 tile on FOUR wavefronts (64 x 96 each, one per SIMD, 29 % fewer fragment bytes out of LDS):
-    // slower alone (20.3 against 19.8 us at 2 048 rows) but +3.6 % games/s in the bench, same box (29.3-29.4 k against 28.3 k;
-    // 128 x 48 per wavefront, config 12, the same); the F-wide layers keep the 8 wavefronts (6 / 12 there: 28.7-28.8 k).
+    // Above 1 024 rows every layer runs the 128 x 192 tile on 8 wavefronts (config 11).  (Mid round 4 the 2F-wide layer ran it on
+    // FOUR wavefronts, config 6 -- 64 x 96 each, one per SIMD, 29 % fewer fragment bytes out of LDS: slower alone, 20.3 against
+    // 19.8 us at 2 048 rows, but +3.6 % games/s in the bench of that moment because the other session's small step-kernel
+    // workgroups fitted beside it.  Since the output layers and the step are ONE launch of 6-wavefront workgroups that
+    // advantage is gone: same box, 11 for every layer 29.6-30.2 k games/s against 29.4-29.8 k, profiles/r04_gemm_configs.txt (4).)
     // ... and up to 1 024 rows, where a layer is a latency chain, the wave-specialised forms of round 3's small tiles (two or four
     // wavefronts that only issue the DMA pieces: 3-15 % less time alone, tools/gemm_small_ab.sh in profiles/r04_gemm_configs.txt)
-    config = m <= 384 ? 41 : m <= 640 ? (wide ? 42 : 41) : m <= 896 ? (wide ? 44 : 42) : m <= 1024 ? (wide ? 43 : 42) : (wide ? 6 : 11);
+    config = m <= 384 ? 41 : m <= 640 ? (wide ? 42 : 41) : m <= 896 ? (wide ? 44 : 42) : m <= 1024 ? (wide ? 43 : 42) : 11;
     // The 64-channel net (K = 2 688, N = 5 376 / 2 688: four times the flops per layer): there the 256 x 192 tile
     // (64 x 96 per wavefront, 2-deep ring, 112 KB) pays -- BASELINE config 4 (2 x 2 048 rows) 862 -> 925-939 games/s,
     // config 5's per-GPU share (2 x 4 096 rows) 3 271 -> 3 671 (hipBLASLt: 911-919 / 3 736), profiles/r03_gemm_configs.txt

@@ -310,7 +310,7 @@ def test_to_records_round_trip():
 def test_tile_choice_of_a_session_alone_on_the_device():
     """InferenceNet._alone_config (host logic, no GPU): only a session that has the device to itself asks for the
     small tiles, only between 1 025 and 1 728 rows for both layer widths (96 x 96, wave-specialised); beyond, the wave-specialised
-    128 x 96 tile for the F-wide layers and 128 x 192 tile for the 2F-wide layer (the automatic choice there, config 6 on four
+    128 x 96 tile for the F-wide layers and 128 x 192 tile for the 2F-wide layer (the automatic choice there, config 11 on eight
     wavefronts, is the one that wins beside a second session); otherwise the automatic choice (0) stands."""
     from c4a0_amd.nn import InferenceNet
 
