@@ -25,6 +25,10 @@ res = c4a0_amd.play_games(reqs, 4096, 100, 6.6, 0.01, cb, stats=stats)
 dt = time.perf_counter() - t0
 print(f"callback mode: {n} games, n_mcts=100: {dt:.1f} s = {n / dt:.0f} games/s, {stats['sims'] / dt / 1e6:.2f} M sims/s, {stats['steps']} steps")
 t0 = time.perf_counter()
+c4a0_amd.play_games(reqs, 4096, 100, 6.6, 0.01, lambda _m, x: net.forward_numpy(x), stats=stats)   # a caller whose model IS an InferenceNet (nn.py:119-130 entry point)
+dt = time.perf_counter() - t0
+print(f"callback mode, callback = InferenceNet.forward_numpy (same fp32 weights; one HIP-graph replay per call): {dt:.1f} s = {n / dt:.0f} games/s")
+t0 = time.perf_counter()
 res2 = c4a0_amd.play_games(reqs, 4096, 100, 6.6, 0.01, evaluator=net, stats=stats)
 dt = time.perf_counter() - t0
 print(f"device mode (default resident games = {stats['n_slots']}): {n} games: {dt:.2f} s = {n / dt:.0f} games/s, {stats['steps']} steps")
