@@ -55,10 +55,13 @@ for backend in ("hip0", "hipblaslt0"):
                        "lds_bank_conflict_frac_of_lds_cycles": v.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, v.get("SQ_LDS_IDX_ACTIVE", 0)),
                        "tcp_to_tcc_read_GBps": v.get("TCP_TCC_READ_REQ_sum", 0) * 64.0 / ns if ns else None}
         res[k] = {"derived": derived, "counters": {c: x for c, x in v.items() if c != "dispatches_averaged"}}
-    tot = sum(r["derived"].get("duration_us", 0) for r in res.values())
+    # weighted by time AND by launches per forward pass (a kernel name that serves all three hidden layers counts three times)
+    for k, r in res.items():
+        r["derived"]["launches_averaged"] = merged[k].get("dispatches_averaged", 1)
+    tot = sum(r["derived"].get("duration_us", 0) * r["derived"]["launches_averaged"] for r in res.values())
     if tot:
         out["backends"][backend] = {"kernels": res, "evaluator_mfma_busy_frac_of_chip_time_weighted":
-                                    sum(r["derived"].get("duration_us", 0) * r["derived"].get("mfma_busy_frac_of_chip", 0) for r in res.values()) / tot}
+                                    sum(r["derived"].get("duration_us", 0) * r["derived"]["launches_averaged"] * r["derived"].get("mfma_busy_frac_of_chip", 0) for r in res.values()) / tot}
     else:
         out["backends"][backend] = {"kernels": res}
 print(json.dumps(out, indent=1))
