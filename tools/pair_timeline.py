@@ -126,14 +126,12 @@ tag_idx = {}
 for d in L2:
     tag_idx.setdefault(d["kind"], {})
     tag_idx[d["kind"]].setdefault(d["tag"], len(tag_idx[d["kind"]]))
-mid = L2[len(L2) // 2]["t0"]
-win = [d for d in L2 if mid <= d["t0"]]
-towers = [d for d in win if d["kind"] == "T"]
+mid = L2[len(L2) // 2]["t0"]                       # a window in the middle of the recording: 2 x rounds tower launches (both sessions)
+towers = [d for d in L2 if d["kind"] == "T" and d["t0"] >= mid]
 t_start = towers[0]["t0"] if towers else mid
 t_end = towers[min(len(towers) - 1, 2 * args.rounds)]["t0"] if towers else mid + 1000
 print(f"window of {args.rounds} rounds from t = {t_start:.1f} us; columns: kind/tag#, workgroups, CUs used, first start .. last end (us), "
       f"last workgroup start - first (wait for CUs), mean workgroup duration, CUs shared with the launches running at its start")
-active = []
 for d in L2:
     if d["t0"] < t_start - 200 or d["t0"] > t_end:
         continue
