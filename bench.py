@@ -188,6 +188,38 @@ def whole_job(args, device, real_stdout):
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
 
+def run_child(cmd, timeout_s: float):
+    """A time-limited child process that can never hold the headline hostage: output goes to temporary FILES
+    (no pipe to drain), the child is polled against a deadline, and a child that does not die after SIGKILL -- e.g. one
+    stuck in an uninterruptible GPU wait -- is abandoned after 10 more seconds instead of waited for.  (subprocess.run's
+    own timeout kills and then waits WITHOUT a limit.)  Returns (returncode or None, stdout, stderr tail)."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryFile() as fo, tempfile.TemporaryFile() as fe:
+        p = subprocess.Popen(cmd, stdout=fo, stderr=fe, cwd=ROOT)
+        deadline = time.monotonic() + timeout_s
+        rc = None
+        while rc is None and time.monotonic() < deadline:
+            try:
+                rc = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                pass
+        timed_out = rc is None
+        if timed_out:
+            p.kill()                      # exactly this pid
+            try:
+                p.wait(timeout=10.0)
+            except subprocess.TimeoutExpired:
+                pass                      # abandoned: the line below is printed regardless
+        fo.seek(0)
+        fe.seek(0)
+        out, err = fo.read().decode("utf-8", "replace"), fe.read().decode("utf-8", "replace")
+    if timed_out:
+        raise TimeoutError(f"child exceeded {timeout_s:.0f} s: {err[-200:]}")
+    return rc, out, err
+
+
 def other_config_legs(args, sessions) -> dict:
     """The other single-GPU shapes under the driver's clock: after the headline has been measured (and
     is already in `out`), short legs in FRESH child processes, each under a time limit so that none can cost the
@@ -207,13 +239,18 @@ def other_config_legs(args, sessions) -> dict:
         "reference_default_job": base + ["--whole-job", "--whole-job-modes", "device_mode,numpy_callback"],
     }
     res = {}
+    t_all = time.perf_counter()
     for name, cmd in legs.items():
         t0 = time.perf_counter()
+        left = args.other_configs_total_seconds - (t0 - t_all)     # the legs TOGETHER are bounded too
+        if left < 20.0:
+            res[name] = {"error": f"skipped: the legs' total budget of {args.other_configs_total_seconds:.0f} s is spent", "leg_seconds": 0.0}
+            continue
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.other_configs_seconds, cwd=ROOT)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode != 0 or not line:
-                raise RuntimeError(f"child exited with {r.returncode}: {r.stderr[-300:]}")
+            rc, stdout, stderr = run_child(cmd, min(args.other_configs_seconds, left))
+            line = [l for l in stdout.splitlines() if l.startswith("{")]
+            if rc != 0 or not line:
+                raise RuntimeError(f"child exited with {rc}: {stderr[-300:]}")
             d = json.loads(line[-1])
             if name == "reference_default_job":
                 res[name] = {"workload": d["config"]["workload"],
@@ -338,6 +375,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs for the other single-GPU shapes (BASELINE config 4, config 5's per-GPU share, the reference's default job) that the default N = 1 run attaches as `other_configs`")
     ap.add_argument("--other-configs-seconds", type=float, default=150.0, help="time limit of EACH other_configs leg (a child process)")
+    ap.add_argument("--other-configs-total-seconds", type=float, default=360.0, help="time limit of all other_configs legs TOGETHER (legs past it are skipped)")
     ap.add_argument("--whole-job-games", type=int, default=1700)
     ap.add_argument("--whole-job-n-mcts", type=int, default=1400)
     args = ap.parse_args()
@@ -643,7 +681,8 @@ def main():
                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": fl * G * timed_rounds / elapsed / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                    "note": "evaluator FLOPs over the WHOLE wall time of the timed steps (tree kernels and launch gaps included): a lower bound on the evaluator's own rate",
-                   "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src, "hidden_layer_gemm": net.gemm},
+                   "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src, "hidden_layer_gemm": net.gemm,
+                   "path": net.path},   # "hip" = hand-written tower + GEMM + output kernels; "torch" = PyTorch / library kernels somewhere in the chain
         }
         if allgather is not None:
             out["sample_allgather"] = allgather
@@ -658,12 +697,11 @@ def main():
             torch.cuda.empty_cache()
             try:
                 limit = max(120.0, 8.0 * args.cpu_baseline_seconds)
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--n-mcts", str(n_iter), "--blocks", str(args.blocks),
-                                    "--channels", str(args.channels), "--cpu-baseline-seconds", str(args.cpu_baseline_seconds)],
-                                   capture_output=True, text=True, timeout=limit, cwd=ROOT)
-                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                if r.returncode != 0 or not line:
-                    raise RuntimeError(f"child exited with {r.returncode}: {r.stderr[-300:]}")
+                rc, stdout, stderr = run_child([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--n-mcts", str(n_iter), "--blocks", str(args.blocks),
+                                                "--channels", str(args.channels), "--cpu-baseline-seconds", str(args.cpu_baseline_seconds)], limit)
+                line = [l for l in stdout.splitlines() if l.startswith("{")]
+                if rc != 0 or not line:
+                    raise RuntimeError(f"child exited with {rc}: {stderr[-300:]}")
                 out["cpu_baseline"] = json.loads(line[-1])
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}

@@ -19,7 +19,7 @@ STATUS_NAMES = {
 FLAG_NO_MOVES = 1
 FLAG_ONE_SIM_PER_STEP = 2
 MAX_SAMPLES_PER_GAME = 43
-ABI_VERSION = 6   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
+ABI_VERSION = 7   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
 
 
 class C4Error(RuntimeError):
@@ -96,6 +96,7 @@ SIGNATURES = {
     "c4_apply_temperature": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "c4_conv_tower_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp]),
     "c4_linear_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
+    "c4_linear_bf16_tile_map": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), C.c_uint32, _P(C.c_uint32)]),
     "c4_planes_from_f32": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),
     "c4_head_out_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "c4_dirichlet": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_uint64, _vp, _vp]),

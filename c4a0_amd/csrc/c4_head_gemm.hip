@@ -66,6 +66,18 @@ struct GemmParams {
   p.ldy = a_ld >> 16; p.relu = a_flags & 0xFFu; p.xn_log2 = (a_flags >> 8) & 0xFFu; p.xcd_mask = (a_flags >> 16) & 0xFFu;              \
   p.xcd_shift = a_flags >> 24; p.rm = a_rmrn & 0xFFFFu; p.rn = a_rmrn >> 16; p.rn_magic = a_magic
 
+// Tile of block `blk` (see GemmParams).  ONE definition for the kernels and for the host-side map that the CPU tests walk
+// (c4_linear_bf16_tile_map): idx / rn is a multiplication by rn_magic = 2^32 / rn + 1, exact while idx * rn < 2^32 -- except
+// for rn == 1, whose magic does not fit 32 bits (the truncated magic sent every block but the first to tn = idx,
+// past N): there the quotient is idx itself.  All operands are wavefront-uniform: scalar instructions on the device.
+__host__ __device__ __forceinline__ void tile_of_block(uint32_t blk, uint32_t xcd_mask, uint32_t xcd_shift, uint32_t xn_log2, uint32_t rm, uint32_t rn,
+                                                       uint32_t rn_magic, int& tm, int& tn) {
+  const uint32_t xcd = blk & xcd_mask, idx = blk >> xcd_shift;
+  const uint32_t qn = rn == 1u ? idx : (uint32_t)(((uint64_t)idx * rn_magic) >> 32);   // idx / rn
+  tm = (int)((xcd >> xn_log2) * rm + qn);
+  tn = (int)((xcd & ((1u << xn_log2) - 1u)) * rn + (idx - qn * rn));
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -226,10 +238,8 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
   // ---- which tile: blocks b and b + 8 share an XCD (round-robin dispatch; speed only).  Give each
   // XCD a rectangle of tiles so that its private L2 sees each X row block and W column block once.
   // (One straight-line formula, no division: the kernel's arguments are fetched by one scalar load at its top.)
-  const uint32_t blk = blockIdx.x, xcd = blk & p.xcd_mask, idx = blk >> p.xcd_shift;
-  const uint32_t qn = __umulhi(idx, p.rn_magic);                // idx / rn
-  const int tm = (int)((xcd >> p.xn_log2) * p.rm + qn);
-  const int tn = (int)((xcd & ((1u << p.xn_log2) - 1u)) * p.rn + (idx - qn * p.rn));
+  int tm, tn;
+  tile_of_block(blockIdx.x, p.xcd_mask, p.xcd_shift, p.xn_log2, p.rm, p.rn, p.rn_magic, tm, tn);
   const int tm0 = tm * BM, tn0 = tn * BN;
 
   // ---- DMA source offsets (bytes from x / w) of this lane for its L pieces of a k-tile; a k-tile
@@ -470,10 +480,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void c4_head_gemm32_kernel(C4_GEMM
   const int li = lane & 15, lg = lane >> 4;
   const bool short_wave = R != 0 && wave >= R;                // issues L - 1 pieces per k-tile
 
-  const uint32_t blk = blockIdx.x, xcd = blk & p.xcd_mask, idx = blk >> p.xcd_shift;
-  const uint32_t qn = __umulhi(idx, p.rn_magic);                // idx / rn
-  const int tm = (int)((xcd >> p.xn_log2) * p.rm + qn);
-  const int tn = (int)((xcd & ((1u << p.xn_log2) - 1u)) * p.rn + (idx - qn * p.rn));
+  int tm, tn;
+  tile_of_block(blockIdx.x, p.xcd_mask, p.xcd_shift, p.xn_log2, p.rm, p.rn, p.rn_magic, tm, tn);
   const int tm0 = tm * BM, tn0 = tn * BN;
 
   auto swz = [](int row) __attribute__((always_inline)) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; };   // T = {0, 2, 3, 1}
@@ -583,7 +591,7 @@ inline uint32_t set_tile_order(GemmParams& p, uint32_t tiles_m, uint32_t tiles_n
     const uint64_t rows = (uint64_t)(tiles_m / xm) * bm + (uint64_t)(tiles_n / xn) * bn;
     if (rows < best) { best = rows; p.xcd_mask = 7; p.xcd_shift = 3; p.xn_log2 = l2; p.rm = tiles_m / xm; p.rn = tiles_n / xn; }
   }
-  p.rn_magic = (uint32_t)((1ull << 32) / p.rn + 1);            // exact for idx * rn < 2^32
+  p.rn_magic = p.rn == 1 ? 0u : (uint32_t)((1ull << 32) / p.rn + 1);   // exact for idx * rn < 2^32; rn == 1: see tile_of_block
   return tiles_m * tiles_n;
 }
 
@@ -594,6 +602,8 @@ int launch_common(K k, GemmParams p, int threads, int lds_bytes, hipStream_t str
     if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_linear_bf16: LDS opt-in: ") + hipGetErrorString(e));
   }
   const uint32_t tiles = set_tile_order(p, (p.M + BM - 1) / BM, p.N / BN, BM, BN);
+  if (p.rm > 0xFFFFu || p.rn > 0xFFFFu)   // rm and rn travel as 16-bit halves of one kernel argument
+    return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: more than 65 535 tiles along one dimension of an XCD's rectangle (m too large for this tile)");
   k<<<dim3(tiles), dim3(threads), lds_bytes, stream>>>(p.x, p.w, p.bias, p.y, p.M, p.N | (p.K << 16), p.ldx | (p.ldy << 16),
                                                          (p.relu ? 1u : 0u) | (p.xn_log2 << 8) | (p.xcd_mask << 16) | (p.xcd_shift << 24), p.rm | (p.rn << 16), p.rn_magic);
   const hipError_t e = hipGetLastError();
@@ -638,6 +648,26 @@ extern "C" int c4_debug_gemm_phases(double* phase_us, double* span_us, int reset
 #endif
 
 C4_TL_SETTER(c4_debug_timeline_gemm)
+
+// The block -> tile map of a launch, computed on the host with the kernels' own formula (tile_of_block): tiles_out[2 b] = tm,
+// tiles_out[2 b + 1] = tn of block b.  No device is touched: the CPU suite walks every tile grid c4_linear_bf16 accepts and
+// checks that the map is a bijection onto the grid (tests/test_abi_and_results.py).
+extern "C" int c4_linear_bf16_tile_map(uint32_t m, uint32_t n, uint32_t bm, uint32_t bn, uint32_t* tiles_out, uint32_t cap_blocks, uint32_t* n_blocks) {
+  if (!n_blocks || bm == 0 || bn == 0 || m == 0 || n == 0 || n % bn) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16_tile_map: bad argument");
+  GemmParams p{};
+  p.M = m; p.N = n;
+  const uint32_t tiles = set_tile_order(p, (m + bm - 1) / bm, n / bn, bm, bn);
+  *n_blocks = tiles;
+  if (p.rm > 0xFFFFu || p.rn > 0xFFFFu) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16_tile_map: more than 65 535 tiles along one dimension");
+  if (!tiles_out) return C4_OK;
+  if (cap_blocks < tiles) return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16_tile_map: output too small");
+  for (uint32_t b = 0; b < tiles; b++) {
+    int tm, tn;
+    tile_of_block(b, p.xcd_mask, p.xcd_shift, p.xn_log2, p.rm, p.rn, p.rn_magic, tm, tn);
+    tiles_out[2 * b] = (uint32_t)tm; tiles_out[2 * b + 1] = (uint32_t)tn;
+  }
+  return C4_OK;
+}
 
 extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float* bias_dev, void* y_dev, uint32_t m, uint32_t n,
                               uint32_t k, uint32_t ldx, uint32_t ldy, uint32_t relu, uint32_t config, void* stream) {

@@ -14,6 +14,8 @@ kernel reads and writes.
 """
 from __future__ import annotations
 
+import threading
+import warnings
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -115,11 +117,18 @@ def pack_tower_weights(conv_w, conv_b, channels: int):
     return p0.contiguous(), pw.contiguous(), bias.contiguous()
 
 
+class EvaluatorFallbackWarning(UserWarning):
+    """An InferenceNet that leaves the hand-written HIP kernels (channels not 32 / 64, or not bf16, or not on a HIP device)."""
+
+
 class InferenceNet:
     """Device-resident evaluator: planes[G,2,6,7] -> (policy_logprobs[G,7] f32, q[G,2] f32).
 
     `hip_tower=True` (default on a HIP device in bf16 with 32 or 64 channels) runs the conv tower
-    as the hand-written MFMA kernel `c4_conv_tower_bf16`; otherwise PyTorch-ROCm convs."""
+    as the hand-written MFMA kernel `c4_conv_tower_bf16`; otherwise PyTorch-ROCm convs + the library GEMM -- a path
+    whose low bits depend on the batch (`batch_invariant` False), slower, and never the one the parity suite certifies.
+    Leaving the hand-written kernels is therefore LOUD: `strict=True` refuses (ValueError), the default warns once per
+    construction (EvaluatorFallbackWarning) and `path` says which one runs ("hip" | "torch"; the bench line carries it)."""
 
     latency_mode = False  # True while ONE session plays alone on the device (api._play sets it): the narrow layers of a
                           # > 1 024-row batch then use the 128 x 96 tile (12.7 vs 16.8 us alone at 1 700 rows; beside a
@@ -131,7 +140,8 @@ class InferenceNet:
                        # waits cross-stream events there)
 
     def __init__(self, model: ConnectFourNet, device: torch.device, dtype: torch.dtype = torch.bfloat16,
-                 hip_tower: Optional[bool] = None, gemm: Optional[str] = None, gemm_config=None, tower_config: int = 0):
+                 hip_tower: Optional[bool] = None, gemm: Optional[str] = None, gemm_config=None, tower_config: int = 0,
+                 strict: bool = False):
         """gemm: "hip" (the hand-written MFMA GEMM, default with the HIP tower) or "hipblaslt" (PyTorch's library GEMM, an
         A/B switch: its low bits depend on the batch shape).  gemm_config: c4_linear_bf16's tile configuration, one number or
         "wide,narrow" (the merged 2F-wide first layer, the F-wide layers); tower_config: c4_conv_tower_bf16's workgroup
@@ -144,6 +154,15 @@ class InferenceNet:
         if hip_tower and not can_tower:
             raise ValueError("hip_tower needs a HIP device, bf16 and 32 or 64 channels")
         self.hip_tower = can_tower if hip_tower is None else bool(hip_tower)
+        if not self.hip_tower and hip_tower is None and self.device.type == "cuda":
+            # nobody asked for PyTorch's kernels (hip_tower=False does: the A/B switch of the tests): say so
+            why = (f"{self.channels} channels (the HIP tower and GEMM are written for 32 and 64)" if dtype == torch.bfloat16
+                   else f"dtype {dtype} (the HIP kernels compute in bf16)")
+            msg = (f"InferenceNet: {why}: this evaluator runs on PyTorch's convolutions and the library GEMM, not on the "
+                   "hand-written HIP kernels -- slower, and a position's low bits depend on the batch it is evaluated in")
+            if strict:
+                raise ValueError(msg + " (strict=True)")
+            warnings.warn(msg, EvaluatorFallbackWarning, stacklevel=2)
         conv0 = model.conv[0]
         self.conv_w = [conv0.weight.detach().float()]
         self.conv_b = [conv0.bias.detach().float()]
@@ -196,6 +215,9 @@ class InferenceNet:
         if gemm == "hip" and not (self.hip_tower and (42 * self.channels) % 192 == 0):
             raise ValueError("gemm='hip' needs the HIP tower (bf16, 32 or 64 channels on a HIP device)")
         self.gemm = gemm
+        if strict and gemm != "hip":
+            raise ValueError("InferenceNet(strict=True): gemm='hipblaslt' leaves the hand-written GEMM (its low bits depend on the batch)")
+        self._np_lock = threading.Lock()   # forward_numpy keeps ONE pinned slot, stream and graph set per net
         # every kernel of the evaluator computes a row from that row alone in one fixed order: a position's outputs do
         # not depend on the batch (session.narrow_if_worthwhile may then narrow whenever it likes)
         self.batch_invariant = self.hip_tower and gemm == "hip"
@@ -216,9 +238,16 @@ class InferenceNet:
             for b in self.pol_b[:-1] + self.val_b[:-1] + ([self.merged_b1] if self.merged_b1 is not None else []):
                 self._bias32[b.data_ptr()] = b.float().contiguous()
 
+    @property
+    def path(self) -> str:
+        """Which kernels run: "hip" = the hand-written tower, GEMM and output kernels; "torch" = any PyTorch / library kernel in the chain."""
+        return "hip" if (self.hip_tower and self.gemm == "hip") else "torch"
+
     @torch.no_grad()
-    def tower(self, planes: torch.Tensor) -> torch.Tensor:
-        """Conv tower -> flattened features [G, 42*C] (cell-major when hip_tower, else "c h w")."""
+    def tower(self, planes: torch.Tensor, latency: Optional[bool] = None) -> torch.Tensor:
+        """Conv tower -> flattened features [G, 42*C] (cell-major when hip_tower, else "c h w").  latency: this call's
+        answer to `latency_mode` (None = the attribute)."""
+        latency = self.latency_mode if latency is None else latency
         if self.hip_tower:
             from ._lib import check
             import ctypes as C
@@ -231,7 +260,7 @@ class InferenceNet:
                                              C.c_void_p(self.tw.data_ptr()), C.c_void_p(self.tbias.data_ptr()),
                                              g, self.channels, self.n_blocks, C.c_void_p(out.data_ptr()),
                                              # alone on the device (latency_mode): 8 boards per workgroup up to 2 048 boards
-                                             self.tower_config or (2 if (self.latency_mode and self.channels == 32 and g <= 2048) else 0),
+                                             self.tower_config or (2 if (latency and self.channels == 32 and g <= 2048) else 0),
                                              C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             return out
         x = planes.to(self.dtype)
@@ -243,14 +272,14 @@ class InferenceNet:
         return x.reshape(x.shape[0], -1)
 
     @torch.no_grad()
-    def forward_hidden(self, planes: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward_hidden(self, planes: torch.Tensor, latency: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Everything but the heads' output layers: planes -> (policy head's last hidden activations, value head's), bf16
         [G, F] row views (column stride 1).  The output layers follow in `forward`, or inside the session's fused output +
         step launch (DeviceSession.round, c4_session_step_head_out)."""
         hook = self.stage_hook
         if hook is not None:
             hook(0)
-        x = self.tower(planes)
+        x = self.tower(planes, latency)
         if hook is not None:
             hook(2)                # after the tower is launched (capture_pair's offset_stage measurements)
         if self.merged_w1 is not None:
@@ -259,7 +288,7 @@ class InferenceNet:
             # session's chain holds an F-wide layer instead of the 2F-wide one: same bits, but every cross-stream edge
             # costs more than the 3.5 us it saves -- the bench halved, 28.0 -> 13.7 k games/s -- and ROCm 7.2's
             # hipStreamEndCapture crashes on a fork from a non-origin stream, tools/capture_nested_fork_repro.py.)
-            h = self._linear_relu(x, self.merged_w1, self.merged_b1)
+            h = self._linear_relu(x, self.merged_w1, self.merged_b1, latency=latency)
             if hook is not None:
                 hook(1)
             f = self.merged_w1.shape[0] // 2
@@ -271,17 +300,22 @@ class InferenceNet:
             if hook is not None:   # no merged first layer (a head without hidden layers): the heavy half ends with the tower
                 hook(1)
         for i, (w, b) in enumerate(pol_rest):
-            p = self._linear_relu(p, w, b)
+            p = self._linear_relu(p, w, b, latency=latency)
             if hook is not None:
                 hook(3 + i)      # after each narrow policy layer (capture_pair's offset_stage)
         for w, b in val_rest:
-            v = self._linear_relu(v, w, b)
+            v = self._linear_relu(v, w, b, latency=latency)
         return p, v
 
     @property
     def fused_step_ok(self) -> bool:
-        """The session may run this evaluator's output layers inside its step launch (c4_session_step_head_out)."""
-        return bool(self.hip_tower) and (42 * self.channels) % 1344 == 0
+        """The session may run this evaluator's output layers inside its step launch (c4_session_step_head_out), i.e. call
+        forward_hidden() + head_out_operands() INSTEAD of forward().  Only while forward() is InferenceNet's own: a subclass
+        that overrides `forward` / `__call__` (counting calls, post-processing logits, observers) must see every evaluation,
+        so for it the session keeps evaluate() -> step() (the same answer as setting
+        DeviceSession.fuse_output_step = False)."""
+        own = type(self).forward is InferenceNet.forward and type(self).__call__ is InferenceNet.__call__
+        return own and bool(self.hip_tower) and (42 * self.channels) % 1344 == 0
 
     def head_out_operands(self):
         """(w_policy, w_value, b_policy f32, b_value f32) of the output layers, as the HIP output kernels take them."""
@@ -289,8 +323,8 @@ class InferenceNet:
 
     @torch.no_grad()
     def forward(self, planes: torch.Tensor, out_logprobs: Optional[torch.Tensor] = None,
-                out_q: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        p, v = self.forward_hidden(planes)
+                out_q: Optional[torch.Tensor] = None, latency: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        p, v = self.forward_hidden(planes, latency)
         if self.hip_tower:
             # both output layers + log-softmax + tanh in one HIP launch, written in place
             from ._lib import check
@@ -347,6 +381,18 @@ class InferenceNet:
         if x.shape[1:] != (2, 6, 7):
             raise ValueError(f"forward_numpy: positions must be [B, 2, 6, 7], got {x.shape}")
         bucket = -(-b // self._NP_BUCKET) * self._NP_BUCKET
+        # ONE pinned slot, stream and graph set per net: two threads calling forward_numpy on the same net (a tournament's
+        # callbacks, the cpu_baseline's evaluator thread beside the main thread) take turns -- the reference's
+        # forward_numpy is re-entrant, this one is serialised
+        with self._np_lock:
+            return self._forward_numpy_locked(x, b, bucket)
+
+    def _forward_numpy_locked(self, x, b: int, bucket: int):
+        import ctypes as C
+        import numpy as np
+
+        from ._lib import check
+
         st = getattr(self, "_np", None)
         if st is None or st["cap"] < bucket:
             cap = max(2048, 1 << (bucket - 1).bit_length())
@@ -368,20 +414,17 @@ class InferenceNet:
                 def body():
                     check(self._L.c4_planes_from_f32(C.c_void_p(st["slot"].data_ptr()), None, 0, C.c_void_p(st["planes"].data_ptr()), bucket,
                                                      C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
-                    # the output kernel's stores go to pinned host memory: no copy after it
-                    self.forward(st["planes"][:bucket], out_logprobs=st["h_lp"][:bucket], out_q=st["h_q"][:bucket])
+                    # the output kernel's stores go to pinned host memory: no copy after it.  latency=True: a host round
+                    # trip, this forward has the chip to itself (an argument of the call, not a mutation of the shared net)
+                    self.forward(st["planes"][:bucket], out_logprobs=st["h_lp"][:bucket], out_q=st["h_q"][:bucket], latency=True)
 
                 st["slot_np"][0], st["slot_np"][1] = st["in"].data_ptr(), 0     # warm-up and capture run on empty boards
-                saved, self.latency_mode = self.latency_mode, True   # a host round trip: this forward has the chip to itself
-                try:
-                    for _ in range(2):      # warm-up outside the capture (lazy module loads, LDS opt-ins)
-                        body()
-                    stream.synchronize()
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=stream, capture_error_mode=CAPTURE_ERROR_MODE):
-                        body()
-                finally:
-                    self.latency_mode = saved
+                for _ in range(2):      # warm-up outside the capture (lazy module loads, LDS opt-ins)
+                    body()
+                stream.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream, capture_error_mode=CAPTURE_ERROR_MODE):
+                    body()
                 st["graphs"][bucket] = g
             if direct:
                 st["slot_np"][0] = x.ctypes.data
@@ -394,12 +437,12 @@ class InferenceNet:
         lp, q = st["h_lp"].numpy()[:b], st["h_q"].numpy()[:b]
         return lp.copy(), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
 
-    def _alone_config(self, m: int, n: int, k: int) -> int:
+    def _alone_config(self, m: int, n: int, k: int, latency: Optional[bool] = None) -> int:
         """Tile configuration of a hidden layer when ONE session has the device to itself (latency_mode): above 1 024
         rows the automatic choice is the fat tile that wins beside a second session's kernels; alone, up to 1 728 rows
         the 96 x 96 tile (at most 2 x 256 workgroups, two per CU) and beyond that the 128 x 96 tile for the F-wide
         layers are faster (c4_head_gemm.hip; every configuration computes the same bits).  0 = automatic."""
-        if not self.latency_mode or m <= 1024:
+        if not (self.latency_mode if latency is None else latency) or m <= 1024:
             return 0
         if k >= 2048:   # the 64-channel net: the automatic 256 x 192 tile for the 2F-wide layer, 128 x 192 for the F-wide ones
             return 0 if n > k else 11   # (alone at 2 048 rows: 31 us against 49)
@@ -410,8 +453,8 @@ class InferenceNet:
 
     use_loader_waves = True   # False: round 3's tile table without the wave-specialised forms (A/B)
 
-    def _pick_config(self, m: int, n: int, k: int) -> int:
-        cfg = self._alone_config(m, n, k)
+    def _pick_config(self, m: int, n: int, k: int, latency: Optional[bool] = None) -> int:
+        cfg = self._alone_config(m, n, k, latency)
         if self.use_loader_waves or k >= 2048:
             return cfg
         wide = n > k
@@ -419,7 +462,8 @@ class InferenceNet:
             return 27 if m <= 384 else ((9 if wide else 27) if m <= 640 else ((23 if wide else 9) if m <= 896 else (10 if wide else 9)))
         return {44: 23, 35: 11, 43: 10}.get(cfg, cfg)
 
-    def _linear_relu(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def _linear_relu(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
+                     latency: Optional[bool] = None) -> torch.Tensor:
         """ReLU(x W^T + b): the hand-written MFMA GEMM, or (gemm="hipblaslt") the library's with the bias
         and ReLU in its epilogue where available."""
         if self.gemm == "hip":
@@ -431,7 +475,7 @@ class InferenceNet:
             y = out if out is not None else torch.empty((m, n), dtype=torch.bfloat16, device=self.device)
             check(self._L.c4_linear_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(self._bias32[b.data_ptr()].data_ptr()),
                                          C.c_void_p(y.data_ptr()), m, n, k, x.stride(0), y.stride(0), 1,
-                                         self.gemm_config[0 if n > k else 1] or self._pick_config(m, n, k),
+                                         self.gemm_config[0 if n > k else 1] or self._pick_config(m, n, k, latency),
                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             return y
         if self.fused_epilogue:

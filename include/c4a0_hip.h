@@ -27,7 +27,7 @@ extern "C" {
  * middle of c4_conv_tower_bf16's arguments, version 5 c4_session_step_head_out).  A consumer compiled against this header checks it once at start-up --
  * `if (c4_abi_version() != C4_ABI_VERSION) refuse` -- because the dynamic linker compares names, not signatures
  * (tests/abi_consumer*.c and c4a0_amd/_lib.py do).  No reference counterpart: the reference's boundary is PyO3. */
-#define C4_ABI_VERSION 6
+#define C4_ABI_VERSION 7
 
 #define C4_N_COLS 7          /* rust/src/c4r.rs:45, lib.rs:28 */
 #define C4_N_ROWS 6          /* rust/src/c4r.rs:44, lib.rs:29 */
@@ -312,6 +312,11 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
  * below 2 GiB.  config 0 = automatic, 1..49 = a specific tile configuration (tools/gemm_probe.py; all compute the same bits). */
 int c4_linear_bf16(const void* x_dev, const void* w_dev, const float* bias_dev, void* y_dev, uint32_t m, uint32_t n,
                    uint32_t k, uint32_t ldx, uint32_t ldy, uint32_t relu, uint32_t config, void* stream);
+/* The block -> tile map c4_linear_bf16 launches with for an m x n output cut into bm x bn tiles (XCD-rectangle order), computed
+ * on the HOST with the kernels' own formula; no device is touched.  tiles_out[2 b] / [2 b + 1] = row / column tile of block b
+ * (tiles_out may be NULL to ask for *n_blocks only).  For tests: the map must be a bijection onto the tile grid. */
+int c4_linear_bf16_tile_map(uint32_t m, uint32_t n, uint32_t bm, uint32_t bn, uint32_t* tiles_out, uint32_t cap_blocks,
+                            uint32_t* n_blocks);
 
 /* The entry of `forward_numpy` (nn.py:119-130: `torch.from_numpy(x).to(device)` under autocast): float32 positions
  * [n_boards][2][6][7] -> the tower's bf16 planes [n_rows_out][2][6][7] (round to nearest even; rows n_boards .. n_rows_out - 1

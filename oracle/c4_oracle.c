@@ -118,6 +118,48 @@ unsigned c4o_legal_mask(const c4o_pos* p) {
   return m;
 }
 
+/* Test infrastructure: the rule functions above over n positions in one C call (tests/test_gpu_elementwise.py compares a
+ * million positions; a Python loop over ctypes calls took minutes).  Each output is what the single-position function returns:
+ * legal mask, terminal state + values (values written only for terminal positions, as c4o_terminal_value does), and the
+ * position after `col[i]` (0, 0 where make_move returns None, c4r.rs:58-72). */
+void c4o_pos_ops_batch(const uint64_t* mask, const uint64_t* value, const int32_t* col, uint64_t n, float c_ply_penalty,
+                       uint64_t* out_mask, uint64_t* out_value, int32_t* out_legal, int32_t* out_term, float* out_q) {
+  for (uint64_t i = 0; i < n; i++) {
+    c4o_pos p = {mask[i], value[i]}, nx = {0, 0};
+    out_legal[i] = (int32_t)c4o_legal_mask(&p);
+    float a = 0.0f, b = 0.0f;
+    out_term[i] = c4o_terminal_value(&p, c_ply_penalty, &a, &b);
+    out_q[2 * i] = a; out_q[2 * i + 1] = b;
+    if (!c4o_make_move(&p, col[i], &nx)) { nx.mask = 0; nx.value = 0; }
+    out_mask[i] = nx.mask; out_value[i] = nx.value;
+  }
+}
+
+/* Test infrastructure: the reference's `random_pos` proptest strategy (c4r.rs:610-629) for n positions -- from the empty
+ * board play up to k < 60 random columns, skipping illegal ones, stopping at a terminal position; every prefix is emitted
+ * (each is a reachable position).  The generator is a splitmix64 stream of `seed`: no claim about the reference's RNG, only
+ * that every position is reachable by legal play. */
+static uint64_t c4o_splitmix64(uint64_t* s) {
+  uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+void c4o_random_positions(uint64_t n, uint64_t seed, uint64_t* out_mask, uint64_t* out_value) {
+  uint64_t s = seed, k = 0;
+  while (k < n) {
+    c4o_pos pos = {0, 0};
+    int len = (int)(c4o_splitmix64(&s) % 60);
+    for (int j = 0; j < len && k < n; j++) {
+      if (c4o_terminal_state(&pos) != C4O_NOT_TERMINAL) break;
+      int mov = (int)(c4o_splitmix64(&s) % 7);
+      c4o_pos nx;
+      if (((c4o_legal_mask(&pos) >> mov) & 1u) && c4o_make_move(&pos, mov, &nx)) pos = nx;
+      out_mask[k] = pos.mask; out_value[k] = pos.value; k++;
+    }
+  }
+}
+
 /* c4r.rs:272-286 */
 void c4o_mask_policy(const c4o_pos* p, float* logits) {
   unsigned legal = c4o_legal_mask(p);

@@ -68,6 +68,10 @@ void c4o_flip_h(const c4o_pos* p, c4o_pos* out);              /* c4r.rs:289-299 
 void c4o_write_planes(const c4o_pos* p, float* buf84);        /* c4r.rs:378-392 */
 int c4o_from_moves(const int* cols, int n, c4o_pos* out);     /* c4r.rs:315-321; 1 ok, 0 illegal */
 uint64_t c4o_win_mask(int i);                                 /* c4r.rs:165-224, i in 0..69 */
+/* test infrastructure: the functions above over n positions per call, and n positions reachable by legal play (c4r.rs:610-629) */
+void c4o_pos_ops_batch(const uint64_t* mask, const uint64_t* value, const int32_t* col, uint64_t n, float c_ply_penalty,
+                       uint64_t* out_mask, uint64_t* out_value, int32_t* out_legal, int32_t* out_term, float* out_q);
+void c4o_random_positions(uint64_t n, uint64_t seed, uint64_t* out_mask, uint64_t* out_value);
 
 /* ---- libm restatement (glibc 2.35 sysdeps/ieee754/flt-32/e_expf.c, e_logf.c) ---- */
 float c4o_expf(float x);

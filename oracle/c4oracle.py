@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
         "c4o_write_planes": (None, [P(Pos), f32p]),
         "c4o_from_moves": (C.c_int, [P(C.c_int), C.c_int, P(Pos)]),
         "c4o_win_mask": (C.c_uint64, [C.c_int]),
+        "c4o_pos_ops_batch": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "c4o_random_positions": (None, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
         "c4o_expf": (C.c_float, [C.c_float]),
         "c4o_logf": (C.c_float, [C.c_float]),
         "c4o_sweep_expf": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
@@ -205,6 +207,26 @@ def terminal_value(pos: Pos, c_ply_penalty: float):
 
 def legal_mask(pos: Pos) -> int:
     return lib().c4o_legal_mask(C.byref(pos))
+
+
+def random_positions_np(n: int, seed: int = 1337):
+    """n positions reachable by legal play (the reference's proptest strategy, c4r.rs:610-629) as (mask, value) uint64 arrays."""
+    mask, value = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    lib().c4o_random_positions(n, seed, mask.ctypes.data, value.ctypes.data)
+    return mask, value
+
+
+def pos_ops_batch(mask: np.ndarray, value: np.ndarray, col: np.ndarray, c_ply_penalty: float):
+    """legal mask, terminal state + values and make_move(col) of n positions in one C call ->
+    (next_mask, next_value, legal int32[n], terminal int32[n], q float32[n, 2])."""
+    n = len(mask)
+    mask, value = np.ascontiguousarray(mask, dtype=np.uint64), np.ascontiguousarray(value, dtype=np.uint64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    om, ov = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    ol, ot, oq = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), np.zeros((n, 2), dtype=np.float32)
+    lib().c4o_pos_ops_batch(mask.ctypes.data, value.ctypes.data, col.ctypes.data, n, c_ply_penalty, om.ctypes.data, ov.ctypes.data,
+                            ol.ctypes.data, ot.ctypes.data, oq.ctypes.data)
+    return om, ov, ol, ot, oq
 
 
 def flip_h(pos: Pos) -> Pos:

@@ -324,3 +324,29 @@ def test_tile_choice_of_a_session_alone_on_the_device():
     # the 64-channel net (k = 2 688): the automatic choice for the 2F-wide layer, the 128 x 192 tile for the F-wide ones
     assert net._alone_config(4096, 2688, 2688) == 11 and net._alone_config(1500, 2688, 2688) == 11
     assert net._alone_config(4096, 5376, 2688) == 0 and net._alone_config(1500, 5376, 2688) == 0
+
+
+def test_gemm_block_to_tile_map_is_a_bijection_for_every_grid():
+    """c4_linear_bf16's block -> tile map (XCD rectangles, idx / rn by multiplication) walked on the host with the kernels' own
+    formula.  ADVICE r4: an XCD rectangle one tile wide (rn == 1; N in {192, 384, 768, 1536}) sent every block but the first
+    past N.  Every (tile shape, m, n) the entry point accepts must map its blocks one-to-one onto the tile grid."""
+    import ctypes as C
+    from c4a0_amd import _lib
+    L = _lib.lib()
+    shapes = [(128, 192), (256, 192), (64, 192), (128, 96), (64, 96), (96, 96), (64, 64), (192, 192), (96, 64)]
+    for bm, bn in shapes:
+        for n in [192 * i for i in (1, 2, 3, 4, 7, 8, 14, 16, 28)] + [2688 * 2]:
+            if n % bn:
+                continue
+            for m in (1, bm, 2 * bm, 3 * bm + 1, 8 * bm, 2048, 1700, 4096, 8 * bm * 5):
+                nb = C.c_uint32(0)
+                _lib.check(L.c4_linear_bf16_tile_map(m, n, bm, bn, None, 0, C.byref(nb)))
+                tiles_m, tiles_n = -(-m // bm), n // bn
+                assert nb.value == tiles_m * tiles_n
+                out = (C.c_uint32 * (2 * nb.value))()
+                _lib.check(L.c4_linear_bf16_tile_map(m, n, bm, bn, out, nb.value, C.byref(nb)))
+                seen = {(out[2 * b], out[2 * b + 1]) for b in range(nb.value)}
+                assert seen == {(i, j) for i in range(tiles_m) for j in range(tiles_n)}, (bm, bn, m, n)
+    # more tiles along m than the packed 16-bit kernel argument holds: refused, not wrapped
+    nb = C.c_uint32(0)
+    assert L.c4_linear_bf16_tile_map(64 * 70001, 192, 64, 64, None, 0, C.byref(nb)) != 0

@@ -76,6 +76,22 @@ def test_strided_operands_and_narrow_layers(ops):
         assert torch.equal(y, _linear(L, part.contiguous(), w2, b[:1344].contiguous()))
 
 
+@pytest.mark.parametrize("n", [192, 384, 768, 1536])
+def test_tile_grids_one_xcd_rectangle_wide(ops, n):
+    """N in {192, 384, 768, 1536}: an XCD's rectangle of tiles is ONE tile wide (rn == 1), where round 4's division by
+    multiplication sent blocks past N.  Several row tiles, every configuration whose tile divides N."""
+    L, x, w, b = ops
+    wn, bn = w[:n].contiguous(), b[:n].contiguous()
+    for m in (2048, 700):
+        guard = torch.full((m + 8, n), 7.0, dtype=torch.bfloat16, device=x.device)   # rows past m must stay untouched
+        ref = torch.relu(x[:m].float() @ wn.float().t() + bn)
+        for config in [0] + CONFIGS:
+            guard.fill_(7.0)
+            y = _linear(L, x[:m], wn, bn, config=config, out=guard[:m])   # every tile width (192, 96, 64) divides a multiple of 192
+            torch.testing.assert_close(y.float(), ref, rtol=2.0 ** -7, atol=2.0 ** -7)
+            assert bool((guard[m:] == 7.0).all()), f"config {config} wrote past the last row"
+
+
 def test_bad_arguments_are_refused(ops):
     from c4a0_amd._lib import C4Error
     L, x, w, b = ops

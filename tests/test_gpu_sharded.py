@@ -112,6 +112,22 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert "cpu_baseline" not in out
 
 
+def test_bench_at_world_size_eight_on_one_gpu(tmp_path):
+    """BASELINE configs 3 / 5 run 8 ranks.  No 8-GPU node is available to the tests, so: `bench.py --gpus 8` exactly as the driver
+    calls it at N = 8 (it starts its own 8 rank processes), all eight on the test box's one GPU over gloo, at a small per-rank size.
+    What must hold is everything but the speed: 8 entries per rank-indexed field, every rank's records present, and the merged
+    result complete and in request order (VERDICT r4 next #3)."""
+    env = dict(os.environ, C4_BENCH_SAME_DEVICE="1", C4_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--rounds-per-step", "128",
+           "--preroll", "1600", "--games-per-gpu", "512"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    out = _check_bench_line(r, 8)
+    assert "cpu_baseline" not in out and out["config"]["parallelism"] == "games sharded id%8"
+    assert len(out["per_rank"]["games_completed"]) == 8 and all(g > 0 for g in out["per_rank"]["games_completed"])
+
+
 def test_bench_over_rccl_at_world_size_one(tmp_path):
     """bench.py's N > 1 branch (barriers, reductions, the sample exchange and its check) over backend
     "nccl" = RCCL, forced on at world size 1 (C4_BENCH_FORCE_DIST): what the 8-GPU node will run, minus peers."""

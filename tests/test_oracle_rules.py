@@ -171,3 +171,32 @@ def test_shift_and_terminal_equals_mask_scan():
             x &= rng.getrandbits(42)
         want = any(bin(x & m).count("1") == 4 for m in masks)
         assert has4(x) == want, hex(x)
+
+
+def test_batch_helpers_equal_the_single_position_functions():
+    """c4o_pos_ops_batch / c4o_random_positions (what the million-position GPU parity test runs against): the batch loop adds
+    nothing of its own, and every generated position is reachable by legal play (value within mask, gravity, alternating counts)."""
+    import ctypes as C
+    n = 20000
+    mask, value = O.random_positions_np(n, seed=5)
+    col = np.random.default_rng(1).integers(-1, 8, size=n).astype(np.int32)
+    wm, wv, wl, wt, wq = O.pos_ops_batch(mask, value, col, 0.01)
+    L = O.lib()
+    colmask = [sum(1 << (r * 7 + c) for r in range(6)) for c in range(7)]
+    for i in range(n):
+        m, v = int(mask[i]), int(value[i])
+        assert v & ~m == 0 and m < (1 << 42)
+        for c in range(7):                                   # gravity: a column's stones are contiguous from the bottom row
+            h = bin(m & colmask[c]).count("1")
+            assert m & colmask[c] == sum(1 << (r * 7 + c) for r in range(h))
+        ply = bin(m).count("1")
+        assert bin(v).count("1") == ply // 2                 # the side to move has made floor(ply / 2) moves
+        p = O.Pos(m, v)
+        assert wl[i] == L.c4o_legal_mask(C.byref(p))
+        a, b = C.c_float(), C.c_float()
+        assert wt[i] == L.c4o_terminal_value(C.byref(p), 0.01, C.byref(a), C.byref(b))
+        if wt[i]:
+            assert (wq[i, 0], wq[i, 1]) == (a.value, b.value)
+        nx = O.Pos()
+        ok = L.c4o_make_move(C.byref(p), int(col[i]), C.byref(nx))
+        assert (int(wm[i]), int(wv[i])) == ((nx.mask, nx.value) if ok else (0, 0))
