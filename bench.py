@@ -156,7 +156,10 @@ def whole_job(args, device, real_stdout):
         return net.forward_numpy(x)
 
     out, ref = {}, None
-    modes = (("device_mode", dict(evaluator=net)), ("device_callback_wrapper", dict(py_eval_pos_cb=c4a0_amd.DeviceCallback(net, device))),
+    modes = (("device_mode", dict(evaluator=net)),
+             # A/B row: the never-reclaimed arena of rounds 1-4 (13 GB for this job) -- what reclaiming the arenas during play costs
+             ("device_mode_never_reclaimed_arena", dict(evaluator=net, reclaim=False)),
+             ("device_callback_wrapper", dict(py_eval_pos_cb=c4a0_amd.DeviceCallback(net, device))),
              ("numpy_callback", dict(py_eval_pos_cb=cb)),
              # EXTENSION rows (not the reference's algorithm, off by default): the evaluation cache answers a leaf
              # whose position the evaluator has already seen without an evaluator row -- same samples, because
@@ -178,7 +181,8 @@ def whole_job(args, device, real_stdout):
         dt = time.perf_counter() - t0
         ref = recs if ref is None else ref
         out[name] = {"games_per_s": n_games / dt, "sims_per_s": st["sims"] / dt, "seconds": dt, "steps": st["steps"],
-                     "samples": int(len(recs)), "samples_identical_to_device_mode": bool(recs.tobytes() == ref.tobytes())}
+                     "samples": int(len(recs)), "samples_identical_to_device_mode": bool(recs.tobytes() == ref.tobytes()),
+                     "arena_reclaim_passes": st.get("reclaim_passes", 0), "arena_reclaim_blocks": st.get("reclaim_blocks", 0)}
         if "eval_cache_entries" in kw:
             out[name]["cache_hit_rate"] = st["eval_cache_hits"] / max(1, st["eval_cache_probes"])
     line = {"metric": "whole-job self-play games/sec, the reference's default job", "value": out["device_mode"]["games_per_s"], "unit": "games/s",

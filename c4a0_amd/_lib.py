@@ -18,6 +18,8 @@ STATUS_NAMES = {
 }
 FLAG_NO_MOVES = 1
 FLAG_ONE_SIM_PER_STEP = 2
+FLAG_RECLAIM = 4          # include/c4a0_hip.h C4_FLAG_RECLAIM: the tree arena is reclaimed while a game is played
+FLAG_NO_RECLAIM = 8       # ... never, also where the default sizing would
 MAX_SAMPLES_PER_GAME = 43
 ABI_VERSION = 7   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
 
@@ -40,13 +42,13 @@ class SampleRec(C.Structure):
 class Config(C.Structure):
     _fields_ = [("n_slots", C.c_uint32), ("blocks_per_slot", C.c_uint32), ("n_mcts_iterations", C.c_uint32),
                 ("c_exploration", C.c_float), ("c_ply_penalty", C.c_float), ("planes_dtype", C.c_uint32),
-                ("flags", C.c_uint32), ("device", C.c_int32)]
+                ("flags", C.c_uint32), ("device", C.c_int32), ("reclaim_period", C.c_uint32)]
 
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("sims", "select_levels", "backup_nodes", "expansions", "moves", "games_done",
                                           "ref_skipped_sims", "samples", "games_started", "step_kernel_ns", "step_launches",
-                                          "eval_cache_probes", "eval_cache_hits")] + \
+                                          "eval_cache_probes", "eval_cache_hits", "reclaim_passes", "reclaim_blocks")] + \
                [("error", C.c_uint32), ("error_slot", C.c_uint32)]
 
     def as_dict(self):
@@ -76,6 +78,7 @@ SIGNATURES = {
     "c4_session_set_timing": (C.c_int, [_vp, C.c_int]),
     "c4_session_counters": (C.c_int, [_vp, _P(Counters)]),
     "c4_session_poll": (C.c_int, [_vp, _P(C.c_uint64), _P(C.c_uint32)]),
+    "c4_session_arena": (C.c_int, [_vp, _P(C.c_uint64), _P(C.c_uint32), _P(C.c_uint32)]),
     "c4_session_sample_counts": (C.c_int, [_vp, _P(C.c_uint32), C.c_uint64]),
     "c4_session_drain_samples": (C.c_int, [_vp, _P(SampleRec), C.c_uint64, _P(C.c_uint64)]),
     "c4_session_pack_samples": (C.c_int, [_vp, _vp, C.c_uint64, _P(C.c_uint64)]),
@@ -121,11 +124,18 @@ def lib() -> C.CDLL:
         import torch  # noqa: F401
 
         L = C.CDLL(LIB_PATH)
+        # C4A0_HIP_LIB (tools/build_variant.py: a library built from ANOTHER revision's kernels for a same-box A/B) may predate
+        # entry points and the ABI version of this binding: only there is that tolerated -- the product library must match exactly
+        diagnostic = "C4A0_HIP_LIB" in os.environ
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)
+            fn = getattr(L, name, None)
+            if fn is None:
+                if diagnostic:
+                    continue
+                raise ImportError(f"{LIB_PATH} does not export {name}")
             fn.restype = res
             fn.argtypes = args
-        if L.c4_abi_version() != ABI_VERSION:
+        if L.c4_abi_version() != ABI_VERSION and not diagnostic:
             raise ImportError(f"{LIB_PATH} implements C ABI version {L.c4_abi_version()}, this binding is written for {ABI_VERSION}")
         # a library compiled from other sources than the ones beside it is refused, not used
         # (C4A0_HIP_LIB names a diagnostic build with its own flags: not compared)

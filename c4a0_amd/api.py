@@ -181,14 +181,19 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
                evaluator: Optional[DeviceEvaluator] = None, device=None, resident_games: Optional[int] = None,
                planes_dtype: Optional[torch.dtype] = None, blocks_per_slot: int = 0,
                stats: Optional[dict] = None, dirichlet: Optional[tuple] = None,
-               concurrent_sessions: Optional[int] = None, eval_cache_entries: int = 0) -> PlayGamesResult:
+               concurrent_sessions: Optional[int] = None, eval_cache_entries: int = 0,
+               reclaim: Optional[bool] = None, reclaim_period: int = 0) -> PlayGamesResult:
     """Play every game of `reqs` to the end with MCTS self-play on the GPU and return the
     training samples (reference pybridge.rs:20-53).  Results are in `reqs` order (the
     reference's order is thread-finishing order, self_play.rs:116).
 
     A callback object with a `.device_evaluator` attribute (e.g. `DeviceCallback`) is played in
     device mode with that evaluator: an unmodified caller (training.py:179-189 passes a callable)
-    gets the fast path by wrapping its network once, without touching the call."""
+    gets the fast path by wrapping its network once, without touching the call.
+
+    Any `n_mcts_iterations` up to 32 200 is accepted, like the reference's heap-allocated tree (mcts.rs:187-206, 332-355): above
+    1 000 iterations per move the tree arenas are reclaimed while the games are played (`reclaim=` True / False forces it on /
+    off, `DeviceSession`; the samples are the same either way)."""
     reqs = list(reqs)
     if py_eval_pos_cb is not None and evaluator is None and getattr(py_eval_pos_cb, "device_evaluator", None) is not None:
         evaluator, py_eval_pos_cb = py_eval_pos_cb.device_evaluator, None
@@ -198,7 +203,7 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
     metas = [GameMetadata(r.game_id, r.player0_id, r.player1_id) for r in reqs]
     recs, counts = _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator,
                          device, resident_games, planes_dtype, blocks_per_slot, stats, dirichlet, concurrent_sessions,
-                         eval_cache_entries, on_device=False)
+                         eval_cache_entries, on_device=False, reclaim=reclaim, reclaim_period=reclaim_period)
     return results_from_records(metas, recs, counts)
 
 
@@ -238,7 +243,8 @@ def merge_parts(n_games: int, parts):
 
 
 def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator, device,
-          resident_games, planes_dtype, blocks_per_slot, stats, dirichlet, concurrent_sessions, eval_cache_entries, on_device):
+          resident_games, planes_dtype, blocks_per_slot, stats, dirichlet, concurrent_sessions, eval_cache_entries, on_device,
+          reclaim=None, reclaim_period=0):
     """Play `reqs` on ONE device.  Returns (records, counts) in request order; `records` is a numpy
     SAMPLE_DTYPE array, or with on_device=True a uint8[n, 64] tensor that never left the GPU (packed
     by k_pack_samples: what the sample all-gather of the multi-GPU path sends)."""
@@ -271,7 +277,7 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
             mine = reqs[p::parts]
             slots = min(len(mine), (n_slots + parts - 1 - p) // parts)
             s = DeviceSession(max(1, slots), n_mcts_iterations, c_exploration, c_ply_penalty, device=device,
-                              planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot)
+                              planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot, reclaim=reclaim, reclaim_period=reclaim_period)
             sessions.append(s)
             s.set_games([(r.game_id, r.player0_id, r.player1_id) for r in mine])
             if dirichlet is not None:   # extension: (alpha, epsilon) root noise; the reference has none

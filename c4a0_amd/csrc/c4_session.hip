@@ -161,6 +161,8 @@ struct Params {
   uint32_t max_sims;              // simulations one game may run in one launch (terminal / cached leaves need no evaluator)
   const float* ln_tab;            // ln_tab[k] = c4_logf((float)k), k < n_ln: the parent-visit term of uct_value (mcts.rs:379)
   uint32_t n_ln;
+  uint32_t half_blocks;           // reclaimed arenas (C4_FLAG_RECLAIM): blocks per half, blocks_per_slot = 2 x this; 0 = never-reclaimed arena
+  unsigned long long* reclaim_ctr;   // [2] passes, blocks copied (k_arena_reclaim)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -577,7 +579,8 @@ C4_DEV void step_body(const Params& p, const uint32_t wave_index, const uint32_t
           }
         }
         const uint32_t nb = n_blocks;
-        if (nb >= p.blocks_per_slot) err = err ? err : C4_ERR_ARENA_OVERFLOW;
+        // (a reclaimed arena is two halves: the bump pointer of the lower one stops at the boundary; half_blocks == 0 otherwise, never a block number)
+        if (nb >= p.blocks_per_slot || nb == p.half_blocks) err = err ? err : C4_ERR_ARENA_OVERFLOW;
         if (!err) {
           // Node::new (mcts.rs:345-355) for the 7 children; lane 7 writes the tail (no links yet)
           reinterpret_cast<uint4*>(blocks + nb)[sub] =
@@ -1067,6 +1070,96 @@ __global__ __launch_bounds__(256) void k_compact_move(Params p, const CompactPla
   if (threadIdx.x == 0) { p.slots[src].state = kIdle; p.slots[src].ordinal = 0xFFFFFFFFu; }
 }
 
+// ------------------------------------------------------------------------------------------
+// Reclaimed arenas (C4_FLAG_RECLAIM).  The reference drops the siblings' subtrees at every move (mcts.rs:187-206: the new
+// root's Rc is the only one left); the never-reclaimed arena keeps them, which is what bounds n_mcts_iterations by the 16-bit
+// child links (43 n + 8 <= 65 535 blocks).  Here a slot's arena is two halves of half_blocks blocks.  A game allocates in one of
+// them; when that half runs short, this kernel -- launched behind every reclaim_period-th step launch, between two steps, when
+// every game waits for the evaluator with a recorded path -- copies what is still reachable into the other half, compactly:
+//   new[0] = the block that holds the root's OWN entry (level 0 of every backup),  new[1] = the root's children block,
+//   then breadth first: the workgroup walks the copied blocks in order; a block's children are copied to the next free
+//   places and its links patched.  An old block's forwarding address goes into its tail's `legal` half-word (written by
+//   expansion, read by nobody), from which the recorded path (entry refs = block << 3 | column) is translated at the end.
+// Reachable blocks number at most (visits of the root + simulations of one launch + 2) <= half_blocks, so the copy always fits.
+// One workgroup of 1 024 threads per slot (128 lane groups of 8: a block is one 16-byte load per lane, as everywhere);
+// slots with room left return after one load.  Which block a node sits in changes nothing a game records.
+// ------------------------------------------------------------------------------------------
+constexpr int kReclaimThreads = 1024;
+__global__ __launch_bounds__(kReclaimThreads) void k_arena_reclaim(Params p, uint32_t min_free) {
+  __shared__ uint32_t s_tail;
+  const uint32_t g = blockIdx.x;
+  if (g >= p.n_slots) return;
+  Slot* st = p.slots + g;
+  const uint32_t state = st->state, arena = st->arena;
+  if (slot_status(state) != kActive) return;
+  const uint32_t H = p.half_blocks;
+  const uint32_t n_blocks = arena & 0xFFFFu, root_block = arena >> 16;
+  const uint32_t cur = n_blocks > H ? H : 0u;             // the half in use (the upper one never holds fewer than H + 1)
+  if (H - (n_blocks - cur) >= min_free) return;           // room until the next look
+  Block* blocks = p.blocks + (size_t)g * p.blocks_per_slot;
+  const uint32_t dst = cur ? 0u : H;
+  const uint32_t tid = threadIdx.x, sub = tid & 7u, grp = tid >> 3;
+  const int gbase = (int)(tid & 63u & ~7u);
+  const uint32_t root_ref = st->root_ref, depth = (state >> 8) & 0xFFu;
+  if (grp == 0) reinterpret_cast<uint4*>(blocks + dst)[sub] = load_block_lane(blocks, root_ref >> 3, sub);
+  if (grp == 1 && root_block) {
+    reinterpret_cast<uint4*>(blocks + dst + 1)[sub] = load_block_lane(blocks, root_block, sub);
+    if (sub == 7) blocks[root_block].t.legal = (uint16_t)(dst + 1);
+  }
+  if (tid == 0) s_tail = dst + (root_block ? 2u : 1u);
+  __syncthreads();
+  uint32_t lo = dst + 1, hi = s_tail;
+  while (lo < hi) {                                       // one level of the tree per trip
+    for (uint32_t i = lo + grp; i < hi; i += kReclaimThreads / 8) {
+      const uint4 tl = sub == 7 ? load_block_lane(blocks, i, 7) : make_uint4(0, 0, 0, 0);   // the copied block's links are still OLD block numbers
+      uint32_t link[7], cnt = 0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        const uint32_t w = k >> 1;
+        const uint32_t word = w == 0 ? tl.x : (w == 1 ? tl.y : (w == 2 ? tl.z : tl.w));
+        link[k] = (shfl_u32(word, gbase + 7) >> (16u * (k & 1u))) & 0xFFFFu;
+        cnt += link[k] ? 1u : 0u;
+      }
+      if (cnt == 0) continue;                             // (group-uniform)
+      uint32_t base = sub == 0 ? atomicAdd(&s_tail, cnt) : 0u;
+      base = shfl_u32(base, gbase);
+      uint4 v[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) if (link[k]) v[k] = load_block_lane(blocks, link[k], sub);
+      uint32_t r = 0, nl[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        nl[k] = 0;
+        if (link[k]) {
+          nl[k] = base + r++;
+          reinterpret_cast<uint4*>(blocks + nl[k])[sub] = v[k];
+          if (sub == 7) blocks[link[k]].t.legal = (uint16_t)nl[k];        // forwarding address (after the load above: one wavefront, program order)
+        }
+      }
+      if (sub == 7) {
+        uint4 t2 = tl;
+        t2.x = nl[0] | (nl[1] << 16); t2.y = nl[2] | (nl[3] << 16); t2.z = nl[4] | (nl[5] << 16); t2.w = nl[6] | (tl.w & 0xFFFF0000u);
+        reinterpret_cast<uint4*>(blocks + i)[7] = t2;
+      }
+    }
+    __syncthreads();                                      // this level's copies (and forwarding addresses) are visible to the workgroup
+    lo = hi; hi = s_tail;
+    __syncthreads();
+  }
+  // the recorded path: level L sits at path[4 (L & 3) + (L >> 2)] (L < 16) or path_deep[L - 16]; level 0 is the root's own entry
+  if (tid <= depth && tid < kMaxPath) {
+    uint32_t* slot_word = tid < kHotPath ? &st->path[4 * (tid & 3u) + (tid >> 2)] : &st->path_deep[tid - kHotPath];
+    const uint32_t ref = *slot_word;
+    *slot_word = tid == 0 ? ((dst << 3) | (root_ref & 7u)) : (((uint32_t)blocks[ref >> 3].t.legal << 3) | (ref & 7u));
+  }
+  if (tid == 0) {
+    st->root_ref = (dst << 3) | (root_ref & 7u);
+    st->arena = hi | ((root_block ? dst + 1u : 0u) << 16);
+    atomicAdd(&p.reclaim_ctr[0], 1ull);
+    atomicAdd(&p.reclaim_ctr[1], (unsigned long long)(hi - dst));
+  }
+}
+
 // Exclusive prefix sum of the per-game sample counts = where each game's records start in the packed
 // array.  One 1024-thread workgroup walks the list with a running carry (n_games is a few 10^4..10^6).
 __global__ __launch_bounds__(1024) void k_sample_offsets(const uint32_t* counts, unsigned long long n_games,
@@ -1271,6 +1364,10 @@ struct c4_session {
   uint32_t* uniq_cell = nullptr;
   uint32_t* uniq_row = nullptr;
   uint32_t* uniq_count = nullptr;
+  // reclaimed arenas (C4_FLAG_RECLAIM): step launches since the last look at the arenas, and the capture they were counted in
+  uint32_t reclaim_period = 0;
+  uint32_t reclaim_count = 0;
+  unsigned long long reclaim_capture_id = 0;
 };
 
 C4_TL_SETTER(c4_debug_timeline_session)
@@ -1358,6 +1455,41 @@ void arena_release(int device, void* ptr, size_t bytes) {
 }
 }  // namespace
 
+// ---- reclaimed arenas (C4_FLAG_RECLAIM, k_arena_reclaim) ----
+constexpr uint32_t kReclaimPeriod = 64;          // step launches between two looks at the arenas
+constexpr uint32_t kReclaimAuto = 1000;          // blocks_per_slot == 0: reclaim above this many iterations per move
+constexpr uint32_t kReclaimMaxSims = 8;          // simulations one game may run per launch in a reclaimed arena (evaluation cache)
+// A half is compacted when fewer than this many blocks are free in it.  Between two looks a game takes at most
+// max_sims blocks per step launch, and two looks are at most 2 x period launches apart (an eager step sequence that runs
+// into a graph replay, or the other way round: each form alone keeps the period, see maybe_reclaim).
+static uint32_t reclaim_min_free(uint32_t period, uint32_t max_sims) { return 2u * period * max_sims + 16u; }
+// What a half must hold at the very least: the live subtree right after a compaction (<= n + max_sims + 2 blocks, + slack) and
+// twice the trigger above, so that a freshly compacted half is not at its next trigger already.
+static uint64_t reclaim_half_min(uint32_t n_iter, uint32_t period, uint32_t max_sims) {
+  return (uint64_t)n_iter + max_sims + 8u + 2ull * reclaim_min_free(period, max_sims);
+}
+static bool reclaim_mode(const c4_config* cfg) {
+  return (cfg->flags & C4_FLAG_RECLAIM) != 0 ||
+         (cfg->blocks_per_slot == 0 && cfg->n_mcts_iterations > kReclaimAuto && !(cfg->flags & (C4_FLAG_NO_MOVES | C4_FLAG_NO_RECLAIM)));
+}
+
+// Called behind every step launch of a reclaimed session: every `period`-th launch is followed by k_arena_reclaim on the same
+// stream.  Launches are counted per capture while the stream is being captured into a HIP graph (the count restarts with the
+// capture, so EVERY graph carries a look behind its first step and every `period` steps after it: replays never run longer
+// than min(period, graph length) steps without one), and continuously otherwise.
+static int maybe_reclaim(c4_session* s) {
+  if (!s->p.half_blocks) return C4_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo(s->stream, &cs, &id) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; id = 0; }
+  if (cs != hipStreamCaptureStatusActive) id = 0;
+  if (id != s->reclaim_capture_id) { s->reclaim_capture_id = id; s->reclaim_count = 0; }
+  if (s->reclaim_count++ % s->reclaim_period != 0) return C4_OK;
+  hipLaunchKernelGGL(k_arena_reclaim, dim3(s->p.n_slots), dim3(kReclaimThreads), 0, s->stream, s->p, reclaim_min_free(s->reclaim_period, s->p.max_sims));
+  HIP_TRY(hipGetLastError());
+  return C4_OK;
+}
+
 static hipError_t reset_clock_acc(unsigned long long* acc_dev) {
   const unsigned long long init[5] = {0ull, 0ull, ~0ull, 0ull, 0ull};   // totals; running min start, max end, helpers done
   return hipMemcpy(acc_dev, init, sizeof init, hipMemcpyHostToDevice);
@@ -1365,8 +1497,21 @@ static hipError_t reset_clock_acc(unsigned long long* acc_dev) {
 
 static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   uint64_t bps = cfg->blocks_per_slot;
-  if (bps == 0) bps = 43ull * (cfg->n_mcts_iterations ? cfg->n_mcts_iterations : 1) + 8;
-  if (bps < 2) bps = 2;
+  const bool reclaim = reclaim_mode(cfg);
+  if (reclaim) {
+    s->reclaim_period = cfg->reclaim_period ? cfg->reclaim_period : kReclaimPeriod;
+    if (bps == 0) {
+      // automatic: 1.5 n blocks beyond the minimum, i.e. a compaction every second or third move of a game
+      // (1 700 slots at n = 1 400: 1.8 GB where the never-reclaimed arena took 13 GB)
+      uint64_t half = reclaim_half_min(cfg->n_mcts_iterations, s->reclaim_period, 2) + 3ull * cfg->n_mcts_iterations / 2;
+      bps = 2 * (half > kMaxBlocksPerSlot / 2 ? kMaxBlocksPerSlot / 2 : half);
+    }
+    s->p.half_blocks = (uint32_t)(bps / 2);
+    bps = 2ull * s->p.half_blocks;
+  } else {
+    if (bps == 0) bps = 43ull * (cfg->n_mcts_iterations ? cfg->n_mcts_iterations : 1) + 8;
+    if (bps < 2) bps = 2;
+  }
   s->cfg.blocks_per_slot = (uint32_t)bps;
   const size_t n = cfg->n_slots;
   const uint32_t games_per_wave = 64u / s->lanes_per_game;
@@ -1395,6 +1540,7 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
       (e = hipMalloc(&p.clock_acc, 5 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc(&p.phase, phase_rows * 16 * sizeof(unsigned long long))) != hipSuccess ||   // + the timing helper workgroups (diagnostic builds stamp them too)
       (e = hipMalloc(&s->ln_tab_dev, (size_t)n_ln * sizeof(float))) != hipSuccess ||
+      (e = hipMalloc(&p.reclaim_ctr, 2 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipHostMalloc(&s->probe_host, sizeof(Globals))) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s->probe_event, hipEventDisableTiming)) != hipSuccess)
     return fail(C4_ERR_HIP, std::string("allocating session (") + std::to_string((n * bps * sizeof(Block)) >> 20) +
@@ -1410,6 +1556,7 @@ static int session_create_on_device(const c4_config* cfg, c4_session* s) {
   HIP_TRY(hipMemset(p.phase, 0, phase_rows * 16 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(p.slots, 0, n * sizeof(Slot)));
   HIP_TRY(hipMemset(p.glob, 0, sizeof(Globals)));
+  HIP_TRY(hipMemset(p.reclaim_ctr, 0, 2 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(p.wave_ctr, 0, (size_t)s->n_waves_cap * CTR_N * sizeof(unsigned long long)));
   memset(s->probe_host, 0, sizeof(Globals));
   return C4_OK;
@@ -1427,10 +1574,23 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
   // 1 500, src/c4a0/main.py:176).  Beyond it a long game could overflow its arena in the middle of a
   // job (C4_ERR_ARENA_OVERFLOW loses the whole call), so the default sizing is refused here, with the
   // reason; a caller who knows its games are short may still pass blocks_per_slot explicitly.
-  if (cfg->blocks_per_slot == 0 && 43ull * cfg->n_mcts_iterations + 8 > kMaxBlocksPerSlot)
-    return fail(C4_ERR_BAD_ARG, "n_mcts_iterations > 1523 is not supported with the default arena: a game's tree arena is limited to "
-                                "65535 blocks (16-bit child links; up to 43 n + 8 blocks per game, never reclaimed during a game). "
-                                "Pass blocks_per_slot explicitly to accept C4_ERR_ARENA_OVERFLOW on long games");
+  // (From round 5 the default sizing switches to a RECLAIMED arena above 1 000 iterations, see C4_FLAG_RECLAIM: the live subtree is at
+  // most n + a few blocks, so two halves of 3 n + 280 blocks serve any game and the links stay 16 bits wide up to n = 32 400.)
+  if (reclaim_mode(cfg)) {
+    const uint32_t period = cfg->reclaim_period ? cfg->reclaim_period : kReclaimPeriod;
+    const uint64_t need = reclaim_half_min(cfg->n_mcts_iterations, period, 2);
+    const uint64_t half = cfg->blocks_per_slot ? cfg->blocks_per_slot / 2 : kMaxBlocksPerSlot / 2;
+    if (cfg->flags & C4_FLAG_NO_MOVES) return fail(C4_ERR_BAD_ARG, "C4_FLAG_RECLAIM: a search that never moves never frees anything (C4_FLAG_NO_MOVES)");
+    if (cfg->flags & C4_FLAG_NO_RECLAIM) return fail(C4_ERR_BAD_ARG, "C4_FLAG_RECLAIM and C4_FLAG_NO_RECLAIM exclude each other");
+    if (period > 4096) return fail(C4_ERR_BAD_ARG, "reclaim_period is limited to 4096 step launches");
+    if (half < need)
+      return fail(C4_ERR_BAD_ARG, "reclaimed arena too small: each half must hold the live subtree (n_mcts_iterations + 16 blocks) and the blocks of 4 x "
+                                  "reclaim_period step launches (" + std::to_string(need) + " blocks per half, i.e. blocks_per_slot >= " + std::to_string(2 * need) +
+                                  "; a half is at most 32 767 blocks: n_mcts_iterations <= " + std::to_string(kMaxBlocksPerSlot / 2 - (need - cfg->n_mcts_iterations)) + ")");
+  } else if (cfg->blocks_per_slot == 0 && 43ull * cfg->n_mcts_iterations + 8 > kMaxBlocksPerSlot)
+    return fail(C4_ERR_BAD_ARG, "n_mcts_iterations > 1523 is not supported with a never-reclaimed arena (C4_FLAG_NO_MOVES / C4_FLAG_NO_RECLAIM): a game's tree arena is limited to "
+                                "65535 blocks (16-bit child links; up to 43 n + 8 blocks per game). "
+                                "Pass blocks_per_slot explicitly to accept C4_ERR_ARENA_OVERFLOW on long searches");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(C4_ERR_NO_DEVICE, "no HIP device visible");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(C4_ERR_BAD_ARG, "device ordinal out of range");
@@ -1451,7 +1611,7 @@ int c4_session_destroy(c4_session* s) {
   if (!s) return C4_OK;
   c4host::DeviceGuard guard(s->cfg.device);
   if (s->stream) (void)hipStreamSynchronize(s->stream); else (void)hipDeviceSynchronize();
-  (void)hipFree(s->p.slots); arena_release(s->cfg.device, s->p.blocks, s->arena_bytes); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob); (void)hipFree(s->p.stamps); (void)hipFree(s->p.clock_acc); (void)hipFree(s->p.phase);
+  (void)hipFree(s->p.slots); arena_release(s->cfg.device, s->p.blocks, s->arena_bytes); (void)hipFree(s->p.wave_ctr); (void)hipFree(s->p.glob); (void)hipFree(s->p.stamps); (void)hipFree(s->p.clock_acc); (void)hipFree(s->p.phase); (void)hipFree(s->p.reclaim_ctr);
   (void)hipFree(s->p.samples); (void)hipFree(s->p.sample_counts); (void)hipFree(s->p.cache);
   (void)hipFree(s->plan_dev); (void)hipFree(s->pairs_dev); (void)hipFree(s->offsets_dev); (void)hipFree(s->ln_tab_dev);
   if (s->total_host) (void)hipHostFree(s->total_host);
@@ -1519,6 +1679,8 @@ int c4_session_set_games(c4_session* s, const c4_game_metadata* reqs, uint64_t n
   // a new list of games may come with new evaluator weights: forget the old evaluations
   if (s->p.cache) HIP_TRY(hipMemset(s->p.cache, 0, ((size_t)s->p.cache_mask + 1) * 64));
   s->seq = 0;
+  s->reclaim_count = 0; s->reclaim_capture_id = 0;
+  HIP_TRY(hipMemset(s->p.reclaim_ctr, 0, 2 * sizeof(unsigned long long)));
   s->probe_pending = false; s->probe_done = 0; s->probe_error = 0;
   return C4_OK;
 }
@@ -1589,6 +1751,10 @@ int c4_session_set_eval_cache(c4_session* s, uint64_t n_entries, uint32_t max_si
   HIP_TRY(hipMemset(s->p.cache, 0, n * 64));   // an all-zero entry does not validate (its dwords XOR to 0, not to the seal constant)
   s->p.cache_mask = (uint32_t)(n - 1);
   if (!single) s->p.max_sims = max_sims_per_step ? (max_sims_per_step > 64 ? 64u : max_sims_per_step) : 6u;   // measured at BASELINE config 2: 4 -> 43.3 k, 6 -> 45.5 k, 8 -> 44.8 k games/s
+  if (s->p.half_blocks) {   // a reclaimed half holds the blocks of 4 x reclaim_period launches: as many simulations per launch as that allows
+    if (s->p.max_sims > kReclaimMaxSims) s->p.max_sims = kReclaimMaxSims;
+    while (s->p.max_sims > 2 && reclaim_half_min(s->p.n_iter, s->reclaim_period, s->p.max_sims) > s->p.half_blocks) s->p.max_sims--;
+  }
   return C4_OK;
 }
 
@@ -1645,7 +1811,7 @@ static int launch_step(c4_session* s, const uint32_t* inverse, const float* answ
   if (inverse) C4_LAUNCH_STEP(c4_step_gather_kernel, launch_gather); else C4_LAUNCH_STEP(c4_step_kernel, launch);
 #undef C4_LAUNCH_STEP
   HIP_TRY(hipGetLastError());
-  return C4_OK;
+  return maybe_reclaim(s);
 }
 
 int c4_session_step(c4_session* s) { return launch_step(s, nullptr, nullptr, 0); }
@@ -1684,7 +1850,7 @@ int c4_session_step_head_out(c4_session* s, const void* hidden_policy_dev, const
   };
   if (s->cfg.planes_dtype == 0) launch(c4_out_step_kernel<float>); else launch(c4_out_step_kernel<uint16_t>);
   HIP_TRY(hipGetLastError());
-  return C4_OK;
+  return maybe_reclaim(s);
 }
 
 int c4_session_set_timing(c4_session* s, int enable) {
@@ -1716,6 +1882,9 @@ int c4_session_counters(c4_session* s, c4_counters* out) {
   out->eval_cache_probes = sum[CTR_PROBES]; out->eval_cache_hits = sum[CTR_HITS];
   out->games_started = g.queue_head < s->n_games ? g.queue_head : s->n_games;
   out->error = g.error; out->error_slot = g.error_slot;
+  unsigned long long rc2[2] = {0, 0};
+  HIP_TRY(hipMemcpy(rc2, s->p.reclaim_ctr, sizeof rc2, hipMemcpyDeviceToHost));
+  out->reclaim_passes = rc2[0]; out->reclaim_blocks = rc2[1];
   // device-clock time of the step kernel: launches already folded in by the following launch,
   // plus the last one from its raw stamps
   unsigned long long acc[2] = {0, 0};
@@ -1792,6 +1961,14 @@ int c4_session_compact(c4_session* s, uint32_t multiple, uint32_t* n_active, uin
   }
   if (n_active) *n_active = plan.n_active;
   if (n_slots_now) *n_slots_now = s->p.n_slots;
+  return C4_OK;
+}
+
+int c4_session_arena(c4_session* s, uint64_t* bytes, uint32_t* blocks_per_slot, uint32_t* reclaim_half_blocks) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  if (bytes) *bytes = s->arena_bytes;
+  if (blocks_per_slot) *blocks_per_slot = s->p.blocks_per_slot;
+  if (reclaim_half_blocks) *reclaim_half_blocks = s->p.half_blocks;
   return C4_OK;
 }
 

@@ -30,7 +30,12 @@ CAPTURE_ERROR_MODE = "thread_local"
 class DeviceSession:
     def __init__(self, n_slots: int, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float,
                  device: Optional[torch.device] = None, planes_dtype: torch.dtype = torch.float32,
-                 blocks_per_slot: int = 0, no_moves: bool = False, one_sim_per_step: bool = False):
+                 blocks_per_slot: int = 0, no_moves: bool = False, one_sim_per_step: bool = False,
+                 reclaim: Optional[bool] = None, reclaim_period: int = 0):
+        """reclaim: True = the tree arena is reclaimed while games are played (C4_FLAG_RECLAIM: the live subtree is copied into the
+        arena's other half when one runs short, as the reference frees dead subtrees at every move, mcts.rs:187-206); None = the
+        library decides (on above 1 000 iterations per move with the default sizing); False with more than 1 523 iterations needs
+        an explicit blocks_per_slot.  reclaim_period: step launches between two looks at the arenas (0 = 64; tests use 1)."""
         if not torch.cuda.is_available():
             raise RuntimeError("c4a0_amd needs a HIP device: the tree kernels have no CPU fallback")
         self.L = _lib.lib()
@@ -44,7 +49,8 @@ class DeviceSession:
         self.n_mcts_iterations = int(n_mcts_iterations)
         cfg = Config(self.n_slots, int(blocks_per_slot), self.n_mcts_iterations, float(c_exploration),
                      float(c_ply_penalty), 0 if planes_dtype == torch.float32 else 1,
-                     (_lib.FLAG_NO_MOVES if no_moves else 0) | (_lib.FLAG_ONE_SIM_PER_STEP if one_sim_per_step else 0), dev_index)
+                     (_lib.FLAG_NO_MOVES if no_moves else 0) | (_lib.FLAG_ONE_SIM_PER_STEP if one_sim_per_step else 0) |
+                     (_lib.FLAG_RECLAIM if reclaim else (_lib.FLAG_NO_RECLAIM if reclaim is False else 0)), dev_index, int(reclaim_period))
         h = C.c_void_p()
         check(self.L.c4_session_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -109,6 +115,12 @@ class DeviceSession:
         self.leaf_models = torch.zeros(self.n_slots, dtype=torch.int64, device=self.device)
         check(self.L.c4_session_bind_leaf_models(self._h, C.c_void_p(self.leaf_models.data_ptr())))
         return self.leaf_models
+
+    def arena(self) -> dict:
+        """How the tree arena was sized: {"bytes", "blocks_per_slot", "reclaim_half_blocks"} (the last 0 = never reclaimed)."""
+        b, bps, half = C.c_uint64(), C.c_uint32(), C.c_uint32()
+        check(self.L.c4_session_arena(self._h, C.byref(b), C.byref(bps), C.byref(half)))
+        return {"bytes": b.value, "blocks_per_slot": bps.value, "reclaim_half_blocks": half.value}
 
     def start(self):
         check(self.L.c4_session_start(self._h))

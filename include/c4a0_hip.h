@@ -70,20 +70,35 @@ typedef struct {
 /* Arguments of self_play() (self_play.rs:39-46) that are fixed for a session, plus sizing. */
 typedef struct {
   uint32_t n_slots;           /* games resident on the GPU and advanced in lock-step */
-  uint32_t blocks_per_slot;   /* tree arena per slot, in 128-byte 7-children blocks; 0 = worst case 43*n_mcts_iterations+8;
-                                 at most 65535 (16-bit child links) */
+  uint32_t blocks_per_slot;   /* tree arena per slot, in 128-byte 7-children blocks, at most 65535 (16-bit child links).
+                                 0 = automatic: up to n_mcts_iterations = 1000 the worst case of a never-reclaimed arena,
+                                 43*n_mcts_iterations+8; beyond that (and up to 32 200) a RECLAIMED arena of two halves of
+                                 2.5*n_mcts_iterations+554 blocks each (see C4_FLAG_RECLAIM) */
   uint32_t n_mcts_iterations; /* self_play.rs:43 */
   float c_exploration;        /* self_play.rs:44 (f32, as pybridge.rs:26) */
   float c_ply_penalty;        /* self_play.rs:45 */
   uint32_t planes_dtype;      /* 0 = float32, 1 = bfloat16: element type of the NN input buffer */
   uint32_t flags;             /* C4_FLAG_* */
   int32_t device;             /* HIP device ordinal */
+  uint32_t reclaim_period;    /* reclaimed arenas only: step launches between two looks at the arenas (0 = 64); tests use 1 */
 } c4_config;
 
 #define C4_FLAG_NO_MOVES 1u   /* never move: mcts.rs test helper `run_mcts` (mcts.rs:469-485) */
 #define C4_FLAG_ONE_SIM_PER_STEP 2u /* exactly one simulation per game per c4_session_step.  Default: a game whose
                                        freshly selected leaf is terminal (no evaluator needed, mcts.rs:92-98) runs that
                                        simulation in the same step; samples are identical either way */
+
+#define C4_FLAG_RECLAIM 4u    /* the tree arena is reclaimed while a game is played, as the reference frees the siblings' subtrees at
+                                 every move (mcts.rs:187-206): a slot's arena is two halves; when the half in use runs short, the
+                                 subtree below the current root (at most n_mcts_iterations + a few blocks) is copied compactly into
+                                 the other half by a kernel of its own that follows every reclaim_period-th step launch on the
+                                 session's stream (also inside HIP-graph captures).  Samples are identical with and without it; what
+                                 it lifts is the limit n_mcts_iterations <= 1523 of the never-reclaimed arena, and the arena shrinks
+                                 from 43 n + 8 to 2 x (2.5 n + 554) blocks per slot.  With blocks_per_slot == 0 the flag is implied
+                                 for n_mcts_iterations > 1000; with an explicit blocks_per_slot that value is BOTH halves. */
+
+#define C4_FLAG_NO_RECLAIM 8u /* keep the never-reclaimed arena where the default sizing would reclaim (n_mcts_iterations > 1000): 43 n + 8
+                                 blocks per slot, refused beyond n = 1523 with the reason */
 
 /* Device-side counters (the reference's progress bars, self_play.rs:352-381, plus the
  * roofline numerators of SURVEY 8d).  Sums over all games since set_games. */
@@ -102,6 +117,8 @@ typedef struct {
   uint64_t step_launches;   /* launches summed in step_kernel_ns */
   uint64_t eval_cache_probes; /* leaves looked up in the evaluation cache (extension, c4_session_set_eval_cache) */
   uint64_t eval_cache_hits;   /* ... and found: simulations that needed no evaluator row */
+  uint64_t reclaim_passes;    /* reclaimed arenas (C4_FLAG_RECLAIM): live subtrees copied into the other half ... */
+  uint64_t reclaim_blocks;    /* ... and the 128-byte blocks those copies moved */
   uint32_t error;           /* first c4_status raised on the device, 0 = none */
   uint32_t error_slot;
 } c4_counters;
@@ -212,6 +229,9 @@ int c4_session_compact(c4_session* s, uint32_t multiple, uint32_t* n_active, uin
 /* GameResult list (types.rs:63-71, mcts.rs:271-313).  Two-call pattern: n_samples of every
  * game (host array of n_games uint32, 0 = unfinished), then the records of finished games
  * packed in reqs order into dst_host (capacity cap records).  Both synchronise the stream. */
+/* How the session's tree arena was sized: its bytes, the blocks per slot, and the blocks per half of a reclaimed arena
+ * (C4_FLAG_RECLAIM; 0 = never-reclaimed arena).  Any of the outputs may be NULL. */
+int c4_session_arena(c4_session* s, uint64_t* bytes, uint32_t* blocks_per_slot, uint32_t* reclaim_half_blocks);
 int c4_session_sample_counts(c4_session* s, uint32_t* counts_host, uint64_t n_games);
 int c4_session_drain_samples(c4_session* s, c4_sample_rec* dst_host, uint64_t cap, uint64_t* n_written);
 /* K6: packs the records of finished games, in reqs order, into the

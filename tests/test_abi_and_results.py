@@ -29,8 +29,8 @@ def test_struct_layouts_match_header():
 
     assert C.sizeof(_lib.SampleRec) == 64 == SAMPLE_DTYPE.itemsize
     assert C.sizeof(_lib.GameMetadataC) == 24
-    assert C.sizeof(_lib.Config) == 32
-    assert C.sizeof(_lib.Counters) == 13 * 8 + 8
+    assert C.sizeof(_lib.Config) == 36          # version 7: + reclaim_period
+    assert C.sizeof(_lib.Counters) == 15 * 8 + 8   # version 7: + reclaim_passes, reclaim_blocks
     assert [n for n, *_ in _lib.SampleRec._fields_] == list(SAMPLE_DTYPE.names)
 
 

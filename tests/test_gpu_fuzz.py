@@ -20,9 +20,10 @@ def test_time_boxed_fuzz_parity_fixed_seed(seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "45", str(seed)], cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    m = re.search(r"fuzz parity ok: (\d+) jobs \((\d+) of them through the numpy callback.*?; (\d+) with the bf16 network.*?\), (\d+) games", r.stdout)
+    m = re.search(r"fuzz parity ok: (\d+) jobs \((\d+) of them through the numpy callback.*?; (\d+) with the bf16 network.*?; (\d+) on arenas reclaimed.*?\), (\d+) games", r.stdout)
     assert m, r.stdout[-1500:]
-    jobs, cb_jobs, net_jobs, games = (int(g) for g in m.groups())
+    jobs, cb_jobs, net_jobs, reclaimed_jobs, games = (int(g) for g in m.groups())
+    assert reclaimed_jobs >= 10, r.stdout[-500:]
     # a 45 s box runs ~300 jobs on an MI355X (profiles/r04_fuzz_parity.txt: 4 132 jobs in 10 minutes); far fewer means the
     # soak did not really run
     assert jobs >= 60 and cb_jobs >= 8 and net_jobs >= 5 and games >= 600, r.stdout[-500:]

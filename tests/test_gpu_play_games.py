@@ -362,19 +362,23 @@ def test_paired_sessions_of_unequal_size_narrow_at_different_checks(n_a, n_b):
     assert np.concatenate(got).tobytes() == want_recs.tobytes()
 
 
-def test_search_width_beyond_the_arena_limit_is_refused_with_a_reason():
-    """beyond n_mcts_iterations = 1523 the provable worst case (43 n + 8 blocks per game)
-    no longer fits the 16-bit child links: the session refuses the default sizing at creation instead
-    of failing in the middle of a job; the widest provable search and an explicit arena are accepted."""
+def test_the_never_reclaimed_arena_still_states_its_limit():
+    """Rounds 1-4 refused n_mcts_iterations > 1523 (43 n + 8 blocks per game no longer fit the 16-bit child links).  Round 5
+    reclaims the arena above 1 000 iterations (tests/test_gpu_reclaim.py), so the default sizing accepts them; the limit remains,
+    with its reason, for a caller that asks for the never-reclaimed arena, whose widest provable search and explicit size still work."""
     from c4a0_amd._lib import C4Error
     from c4a0_amd.session import DeviceSession
 
     for n in (3000, 2000, 1524):
         with pytest.raises(C4Error, match="n_mcts_iterations > 1523"):
-            DeviceSession(2, n, 6.6, 0.01)
-    s = DeviceSession(2, 1523, 6.6, 0.01)                        # 43 * 1523 + 8 = 65497 blocks
+            DeviceSession(2, n, 6.6, 0.01, reclaim=False)
+        s = DeviceSession(2, n, 6.6, 0.01)                       # reclaimed: accepted
+        assert s.arena()["reclaim_half_blocks"] > n
+        s.close()
+    s = DeviceSession(2, 1523, 6.6, 0.01, reclaim=False)         # 43 * 1523 + 8 = 65497 blocks
     s.close()
     s = DeviceSession(2, 2000, 6.6, 0.01, blocks_per_slot=65535)  # the caller's own risk, stated in the message
+    assert s.arena()["reclaim_half_blocks"] == 0
     s.close()
 
 

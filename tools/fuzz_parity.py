@@ -18,6 +18,7 @@ from tests.helpers import hash_eval_np
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20260002)
 t0, n_jobs, n_games_total, n_errs, n_cb_jobs = time.time(), 0, 0, 0, 0
+n_reclaimed_jobs = 0
 
 
 def player(model_id, x):      # every "model" prefers other columns (the oracle calls the same function)
@@ -124,13 +125,18 @@ while time.time() - t0 < budget:
     ids = [rng.choice([0, 1, 42, 43, 2**64 - 1, rng.getrandbits(64), rng.randrange(1000)]) for _ in range(n_games)]
     ids = list(dict.fromkeys(ids))          # the oracle's result dict is keyed by game id
     reqs = [(g, 0, 0) for g in ids]
-    s = DeviceSession(n_slots, n_iter, c_expl, c_ply, planes_dtype=rng.choice([torch.float32, torch.bfloat16]), one_sim_per_step=one_sim)
+    # a third of the jobs on a RECLAIMED arena (C4_FLAG_RECLAIM) with halves near the smallest the library accepts and a look at the
+    # arenas every 1-7 launches: the live subtree is copied into the other half several times per game
+    reclaim = rng.random() < 0.33
+    rperiod = rng.choice([1, 1, 2, 3, 7])
+    rkw = dict(reclaim=True, reclaim_period=rperiod, blocks_per_slot=2 * (n_iter + 10 + 2 * (4 * rperiod + 16) + rng.choice([0, 0, 1, 7, 50]))) if reclaim else {}
+    s = DeviceSession(n_slots, n_iter, c_expl, c_ply, planes_dtype=rng.choice([torch.float32, torch.bfloat16]), one_sim_per_step=one_sim, **rkw)
     s.set_games(reqs)
     if dirichlet:
         s.set_dirichlet(*dirichlet)
     if cache:
         s.set_eval_cache(cache)
-    cfg = dict(n_games=len(ids), n_slots=n_slots, n_iter=n_iter, c_expl=c_expl, c_ply=c_ply, dirichlet=dirichlet, cache=cache, one_sim=one_sim, graph=graph)
+    cfg = dict(n_games=len(ids), n_slots=n_slots, n_iter=n_iter, c_expl=c_expl, c_ply=c_ply, dirichlet=dirichlet, cache=cache, one_sim=one_sim, graph=graph, reclaim=rkw)
     dev_err = None
     try:
         if graph:
@@ -152,8 +158,9 @@ while time.time() - t0 < budget:
         n_errs += 1
         continue
     assert ctr["error"] == 0 and ctr["games_done"] == len(ids), (cfg, ctr)
+    n_reclaimed_jobs += 1 if ctr["reclaim_passes"] else 0
     assert got == oracle_samples_by_game(want), cfg
     n_jobs += 1
     n_games_total += len(ids)
-print(f"fuzz parity ok: {n_jobs} jobs ({n_cb_jobs} of them through the numpy callback, one or several models; {n_fused_jobs} with the bf16 network, fused graph path vs eager), {n_games_total} games in {time.time() - t0:.0f} s; "
+print(f"fuzz parity ok: {n_jobs} jobs ({n_cb_jobs} of them through the numpy callback, one or several models; {n_fused_jobs} with the bf16 network, fused graph path vs eager; {n_reclaimed_jobs} on arenas reclaimed during play), {n_games_total} games in {time.time() - t0:.0f} s; "
       f"{n_errs} more jobs ended in the same panic on both sides")
