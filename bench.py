@@ -192,6 +192,58 @@ def whole_job(args, device, real_stdout):
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
 
+def config1_leg(device):
+    """BASELINE config 1 ("for C1, the CPU ResNet through the numpy callback"): 32 self-play games, n_mcts_iterations = 10,
+    a random-init 1-block / 32-channel ResNet -- the reference's own CPU-runnable plumbing case.  Two figures for the same job:
+    (a) the reference's CPU path restated: the C oracle in the reference's thread topology (self_play.rs:60-106) with the network
+        evaluated ON THE HOST CORES in f32 by PyTorch through the numpy callback, exactly as `forward_numpy` does it
+        (src/c4a0/nn.py:119-130 minus the device copies);
+    (b) this library: `play_games` with the same network on the GPU (bf16, hand-written kernels), whole call.
+    The job is tiny (32 games, ~15 moves of <= 10 simulations each): both figures are latency, not throughput."""
+    import c4a0_amd
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+    from oracle import c4oracle as O
+
+    torch.manual_seed(1337)
+    model = ConnectFourNet(ModelConfig(1, 32, 4, 2)).eval()
+    # ONE intra-op thread: the evaluator thread has a core to itself and the oracle's workers SPIN on theirs (pinned); a PyTorch
+    # thread pool scheduled onto those cores crawls (first version of this leg: minutes instead of seconds on the 16-core box)
+    torch.set_num_threads(1)
+
+    @torch.no_grad()
+    def cpu_forward_numpy(_model_id, x):      # nn.py:119-130 on the host
+        lp, qp, qn = model(torch.from_numpy(x))
+        return np.ascontiguousarray(lp.numpy()), np.ascontiguousarray(qp.numpy()), np.ascontiguousarray(qn.numpy())
+
+    reqs = [(i, 0, 0) for i in range(32)]
+    threads = max(2, min(usable_cores(), 64))
+    O.lib().c4o_set_thread_pinning(1)
+    cpu_s, st = [], None
+    for _ in range(5):
+        t0 = time.perf_counter()
+        _res, st = O.self_play(reqs, 2000, 10, 6.6, 0.01, cpu_forward_numpy, n_threads=threads, topology="async")
+        cpu_s.append(time.perf_counter() - t0)
+    O.lib().c4o_set_thread_pinning(0)
+    cpu_s.sort()
+    net = InferenceNet(model, device, dtype=torch.bfloat16)
+    metas = [c4a0_amd.GameMetadata(*r) for r in reqs]
+    c4a0_amd.play_games(metas, 2000, 10, 6.6, 0.01, evaluator=net, device=device)      # untimed: code objects, LDS opt-ins
+    gpu_s = []
+    stats = {}
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = c4a0_amd.play_games(metas, 2000, 10, 6.6, 0.01, evaluator=net, device=device, stats=stats)
+        gpu_s.append(time.perf_counter() - t0)
+    gpu_s.sort()
+    return {"workload": "BASELINE config 1: 32 self-play games, n_mcts_iterations=10, random-init 1-block/32-ch ResNet (4 policy / 2 value layers)",
+            "cpu_reference_path": {"games_per_s": 32 / cpu_s[2], "seconds_median_of_5": cpu_s[2], "cores": threads, "kind": "port",
+                                   "evaluator": f"f32 PyTorch on the host ({torch.get_num_threads()} threads) through the numpy callback",
+                                   "nn_calls": st["nn_calls"], "mean_nn_batch": st["nn_positions"] / max(1, st["nn_calls"]), "sims": st["sims"]},
+            "hip": {"games_per_s": 32 / gpu_s[2], "seconds_median_of_5": gpu_s[2], "sims": stats["sims"], "steps": stats["steps"],
+                    "samples": int(sum(len(r.samples) for r in res.results)), "evaluator": "bf16, hand-written HIP kernels, device mode (whole play_games call)"}}
+
+
 def run_child(cmd, timeout_s: float):
     """A time-limited child process that can never hold the headline hostage: output goes to temporary FILES
     (no pipe to drain), the child is polled against a deadline, and a child that does not die after SIGKILL -- e.g. one
@@ -241,6 +293,7 @@ def other_config_legs(args, sessions) -> dict:
         "config5_per_gpu_dirichlet": base + ["--blocks", "8", "--channels", "64", "--n-mcts", "200", "--games-per-gpu", "8192", "--steps", "3", "--warmup", "1",
                                              "--dirichlet", "1.0,0.25"],
         "reference_default_job": base + ["--whole-job", "--whole-job-modes", "device_mode,numpy_callback"],
+        "config1": base + ["--config1-only"],
     }
     res = {}
     t_all = time.perf_counter()
@@ -256,7 +309,9 @@ def other_config_legs(args, sessions) -> dict:
             if rc != 0 or not line:
                 raise RuntimeError(f"child exited with {rc}: {stderr[-300:]}")
             d = json.loads(line[-1])
-            if name == "reference_default_job":
+            if name == "config1":
+                res[name] = d
+            elif name == "reference_default_job":
                 res[name] = {"workload": d["config"]["workload"],
                              "device": {k: d["device_mode"][k] for k in ("games_per_s", "sims_per_s", "seconds", "steps", "samples")},
                              "numpy_callback": {k: d["numpy_callback"][k] for k in ("games_per_s", "sims_per_s", "seconds", "steps", "samples", "samples_identical_to_device_mode")}}
@@ -373,6 +428,7 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="internal: compute the cpu_baseline object alone and print it (the bench runs this leg in a child "
                          "process under a time limit, so that the checker can never cost the GPU line)")
+    ap.add_argument("--config1-only", action="store_true", help="internal: BASELINE config 1 (32 games, n = 10, 1-block net) on the host cores and on the GPU, own JSON line")
     ap.add_argument("--whole-job", action="store_true",
                     help="instead of the steady-state bench: the reference's default self-play job, whole, in callback and device modes (own JSON line)")
     ap.add_argument("--whole-job-modes", default="", help="comma-separated subset of the --whole-job modes (default: all; device_mode first: the others are compared with it)")
@@ -401,6 +457,9 @@ def main():
     device = torch.device("cuda", dev_index)
     if args.whole_job:
         return whole_job(args, device, real_stdout)
+    if args.config1_only:
+        os.write(real_stdout, (json.dumps(config1_leg(device)) + "\n").encode())
+        return
     if args.cpu_baseline_only:
         from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
         torch.manual_seed(1337)

@@ -461,8 +461,8 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), MINW) void c4_head_gemm_ker
 //     wavefronts issue one more, and each waits for its own count.
 // Every output element still sees the same chain (k ascending, 32 at a time): same bits as above.
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(64 * WM * WN, 1) void c4_head_gemm32_kernel(C4_GEMM_ARGS) {
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW = 1>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm32_kernel(C4_GEMM_ARGS) {
   C4_GEMM_UNPACK();
   constexpr int BKT = 32;
   constexpr int kWaves = WM * WN;
@@ -611,9 +611,9 @@ int launch_common(K k, GemmParams p, int threads, int lds_bytes, hipStream_t str
   return C4_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW = 1>
 int launch_gemm32(GemmParams p, hipStream_t stream, int device) {
-  return launch_common<BM, BN>(c4_head_gemm32_kernel<BM, BN, WM, WN, NSTAGE>, p, 64 * WM * WN, NSTAGE * (BM + BN) * 32 * 2, stream, device);
+  return launch_common<BM, BN>(c4_head_gemm32_kernel<BM, BN, WM, WN, NSTAGE, MINW>, p, 64 * WM * WN, NSTAGE * (BM + BN) * 32 * 2, stream, device);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int MINW, int NLOAD = 0, int STAG = 0, int WST = 0>
@@ -764,6 +764,10 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     case 47: return launch_gemm<128, 192, 2, 4, 4, 1, 0, 1>(p, st, device); // ... 4-deep ring
     case 48: return launch_gemm<256, 192, 4, 2, 3, 1, 0, 0, 2>(p, st, device); // 256 x 192 on 8 wavefronts (64 x 96 each), split ring 3 X + 2 W stages = 144 KB: 112 workgroups for the 2F-wide layer at 2 048 rows
     case 49: return launch_gemm<256, 192, 2, 2, 3, 1, 0, 0, 2>(p, st, device); // ... on 4 wavefronts (128 x 96 each)
+    // round 5: the 128 x 192 tile in 80 KB or less (32-deep k-tiles), so that TWO workgroups -- one of each session's GEMMs -- share a CU
+    case 50: return launch_gemm32<128, 192, 2, 4, 4, 4>(p, st, device);   // 8 wavefronts (64 x 48), 4-deep ring of 32-deep k-tiles, 80 KB, <= 128 registers
+    case 51: return launch_gemm32<128, 192, 2, 4, 3, 4>(p, st, device);   // ... 3-deep ring, 60 KB
+    case 52: return launch_gemm32<128, 192, 2, 2, 4, 2>(p, st, device);   // 4 wavefronts (64 x 96), 4-deep ring, 80 KB, <= 256 registers
     default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
   }
 }

@@ -9,7 +9,7 @@ for r in $(seq 1 ${2:-2}); do for n in $1; do
   case $n in *:*) lib=${n%%:*}; extra=${n#*:};; esac
   if [ $lib = product ]; then unset C4A0_HIP_LIB; else export C4A0_HIP_LIB=libc4a0_hip_$lib.so; fi
   [ $r = 1 ] && { echo "== $n"; PROBE_ONLY=alone PROBE_CFGS=${3:-11} python tools/gemm_probe.py 2048 2>&1 | grep "alone:"; } | tee -a $O/probe.txt
-  python bench.py --steps 6 --warmup 1 --no-cpu-baseline $BENCH_ARGS $extra 2>/dev/null | python -c "
+  python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-other-configs $BENCH_ARGS $extra 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('%-32s %8.0f games/s  %.4f ms/round' % ('$n', d['value'], d['ms_per_round']))" | tee -a $O/bench.txt
