@@ -36,6 +36,13 @@
 #include "c4_host.hpp"
 #include "c4_timeline.hpp"
 
+#ifndef C4_TOWER_PAIR_SAME_SIMD
+#define C4_TOWER_PAIR_SAME_SIMD 0
+#endif
+#ifndef C4_TOWER_ALT_PRIO
+#define C4_TOWER_ALT_PRIO 0
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -75,7 +82,8 @@ struct Geo {
 // Diagnostic build only (tools/tower_phases.py): where a tower workgroup's time goes.  Stamps (100 MHz device clock, first
 // wavefront of every workgroup): 0 entry, 1 input staged (images zeroed, planes in), 2 conv0 done, 2 + i residual layer i done
 // (barrier passed; the last layer: its stores acknowledged); summed over workgroups, plus the earliest entry and latest exit.
-__device__ unsigned long long c4_tower_clk[32];   // [0] workgroups, [1..24] phase ticks, [30] min entry, [31] max exit
+// (round 5: room for three stamps per layer of the 16-layer 64-channel tower -- k-loop done, epilogue done, pair hand-over passed)
+__device__ unsigned long long c4_tower_clk[80];   // [0] workgroups, [1..60] phase ticks, [78] min entry, [79] max exit
 #define C4_TSTAMP(i) do { if (threadIdx.x == 0) tw_ts[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define C4_TSTAMP(i) do { } while (0)
@@ -244,11 +252,23 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
 // first k-steps of layer L + 1 are requested under the last MFMAs of layer L.  B fragments of k-step s + 1 (one per
 // tile) are read from LDS under the MFMAs of k-step s; the accumulators of all G_TILES tiles live in registers and the
 // epilogue (bias already in, ReLU / residual / convert / store) runs once per layer.
-template <int C, int NB, int G_TILES, int MTW, int kDepth, typename WQ>
+struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
+// kMode (round 5): -1 = kSecond / kLast are run-time flags and the epilogue walks its items one by one (the 8-wavefront kernel: one
+// inlined copy of the layer, 253 registers); 0 / 1 / 2 = first conv of a block / second conv / the tower's last layer as
+// COMPILE-TIME variants whose epilogue requests every residual first and has no branch per item (the 4-wavefront kernel, which
+// has the registers: with the flags at run time each of a wavefront's 24 items was "branch, ds_read_b64, s_waitcnt lgkmcnt(0),
+// 12 vector instructions, branch" -- 1.5 / 2.5 us per layer of serial LDS round trips that a lone wavefront on its SIMD cannot hide).
+// max(v, 0) as ONE instruction (see c4_head_gemm.hip relu1: fmaxf costs a canonicalising v_max first; same result for every v)
+__device__ __forceinline__ float tower_relu1(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+template <int C, int NB, int G_TILES, int MTW, int kDepth, typename WQ, typename Stamp = NoStamp, int kMode = -1>
 __device__ __forceinline__ void tower_layer_stream(const bool kSecond, const bool kLast, const uint4* __restrict__ src, uint4* __restrict__ dst, WQ& wq,
                                                    const bf16x8* __restrict__ w_layer, bool has_next, const float* __restrict__ bias,
                                                    int tile_lo, int m0, int lane, uint16_t* __restrict__ out = nullptr,
-                                                   uint32_t board0 = 0, uint32_t n_boards = 0) {
+                                                   uint32_t board0 = 0, uint32_t n_boards = 0, Stamp&& stamp = NoStamp{}) {
   using G = Geo<C, NB>;
   constexpr int kSteps = 9 * G::KC;
   static_assert(kSteps % kDepth == 0, "the weight ring keeps its phase from layer to layer");
@@ -327,6 +347,47 @@ __device__ __forceinline__ void tower_layer_stream(const bool kSecond, const boo
         __builtin_amdgcn_sched_barrier(0);
       }
   }
+  stamp(1);                                                         // (diagnostic build) the k-loop is done
+  if constexpr (kMode >= 0) {
+    // ---- epilogue, compile-time variants: every residual requested up front, no branch per item
+    constexpr bool kSec = kMode >= 1, kLst = kMode == 2;
+    auto optr = [&](int g, int m) __attribute__((always_inline)) {
+      return reinterpret_cast<uint2*>(&dst[(2 * (m0 + m) + (lg >> 1)) * G::kPlane + base[g]]) + (lg & 1);
+    };
+    uint2 res[G_TILES][MTW];
+    if (kSec) {
+#pragma unroll
+      for (int g = 0; g < G_TILES; g++)
+#pragma unroll
+        for (int m = 0; m < MTW; m++) res[g][m] = *optr(g, m);
+    }
+    // padded column 0 is halo: (cell - 1) & 7 == li & 7 in every tile; the LDS image takes the halo lanes' result as zeros over zeros
+    const bool valid = (li & 7) != 0;
+    const uint32_t vmask = valid ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int g = 0; g < G_TILES; g++) {
+#pragma unroll
+      for (int m = 0; m < MTW; m++) {
+        f32x4 v = acc[g][m];
+        if (kSec) {
+          const uint2 o = res[g][m];                                 // the residual stream: bf16 x4, widened by a shift
+          v[0] = __uint_as_float(o.x << 16) + tower_relu1(v[0]); v[1] = __uint_as_float(o.x & 0xffff0000u) + tower_relu1(v[1]);
+          v[2] = __uint_as_float(o.y << 16) + tower_relu1(v[2]); v[3] = __uint_as_float(o.y & 0xffff0000u) + tower_relu1(v[3]);
+        }
+        uint2 ob = __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4));
+        if (kLst) {
+          const int rc = cell[g] - 1, bcell = 7 * ((rc >> 3) - 1) + (rc & 7) - 1;
+          const uint32_t gb = board0 + (uint32_t)((tile_lo + g) / kTilesPerBoard);
+          if (valid && gb < n_boards) *reinterpret_cast<uint2*>(out + ((size_t)gb * 42 + bcell) * C + 16 * (m0 + m) + 4 * lg) = ob;
+        } else {
+          ob.x &= vmask; ob.y &= vmask;
+          *optr(g, m) = ob;
+        }
+      }
+    }
+    stamp(2);
+    return;
+  }
   // ---- epilogue: lane holds output channels 16 (m0 + m) + 4 lg + {0..3} of its cell of every tile
 #pragma unroll
   for (int g = 0; g < G_TILES; g++) {
@@ -351,6 +412,7 @@ __device__ __forceinline__ void tower_layer_stream(const bool kSecond, const boo
       }
     }
   }
+  stamp(2);                                                         // ... the epilogue
 }
 
 // MS = 1: every wavefront computes all C/16 output-channel tiles of its cell tiles.  MS = 2 (C = 64):
@@ -368,24 +430,28 @@ __device__ __forceinline__ void dma_weights(const void* w, uint32_t bytes, uint4
 }
 
 // ST (C = 64): the residual layers run as tower_layer_stream (weights streamed through a ring, k-steps outside).
-template <int C, int NB, int NT, int MS, bool ST = false>
+// KD (ST only): k-steps of weights in flight in the register ring.
+template <int C, int NB, int NT, int MS, bool ST = false, int KD = 3>
 __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __restrict__ a_planes, const bf16x8* __restrict__ a_w0, const bf16x8* __restrict__ a_w,
                                                              const float* __restrict__ a_bias, uint16_t* __restrict__ a_out, uint32_t a_n_boards, uint32_t a_n_blocks) {
   // flat scalar arguments (12 dwords): preloaded into SGPRs at wavefront launch (build.py: -amdgpu-kernarg-preload-count)
   const TowerParams p{a_planes, a_w0, a_w, a_bias, a_out, a_n_boards, a_n_blocks};
   C4_TL_BEGIN();
 #ifdef C4_PHASE_STAMPS
-  unsigned long long tw_ts[24];
+  unsigned long long tw_ts[64];
   auto tw_flush = [&](int last) {
     if (threadIdx.x == 0) {
       atomicAdd(&c4_tower_clk[0], 1ull);
       for (int i = 0; i < last; i++) atomicAdd(&c4_tower_clk[1 + i], tw_ts[i + 1] - tw_ts[i]);
-      atomicMin(&c4_tower_clk[30], tw_ts[0]);
-      atomicMax(&c4_tower_clk[31], tw_ts[last]);
+      atomicMin(&c4_tower_clk[78], tw_ts[0]);
+      atomicMax(&c4_tower_clk[79], tw_ts[last]);
     }
   };
 #endif
   C4_TSTAMP(0);
+#ifdef C4_PHASE_STAMPS
+  const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   using G = Geo<C, NB>;
   constexpr int MTW = G::MT / MS;
   static_assert(G::MT % MS == 0 && (!G::kStageW || MS == 1), "co-tile split");
@@ -397,7 +463,16 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int m0 = (wave % MS) * MTW;                // first output-channel tile of this wavefront
+  // Which wavefronts form an MS-group (they share cell tiles and split the output channels).  C4_TOWER_PAIR_SAME_SIMD (round 5
+  // experiment): group = wavefronts w and w + NT/64/MS, i.e. (with 8 wavefronts dispatched to SIMDs 0, 2, 1, 3, 0, 2, 1, 3) the
+  // two wavefronts of ONE SIMD, instead of the neighbours w, w + 1 that sit on different SIMDs.
+#if C4_TOWER_PAIR_SAME_SIMD
+  constexpr int kGroups = NT / 64 / MS;
+  const int grp_index = wave % kGroups, grp_member = wave / kGroups;
+#else
+  const int grp_index = wave / MS, grp_member = wave % MS;
+#endif
+  const int m0 = grp_member * MTW;                 // first output-channel tile of this wavefront
   const uint32_t board0 = blockIdx.x * NB;
 
   // A fragments (weights) of the current layer, in registers; conv0 uses the first 3 k-steps
@@ -463,10 +538,10 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
   constexpr int kTilesPerWave = G::kTiles / kWaves;
   constexpr bool kPrefetch = (C == 32);            // a second fragment set: 36 more registers at C = 32, 72 at C = 64 (too many)
   constexpr bool kFuseOut = (C == 32);             // C = 64 has no registers left for the global address arithmetic (it would spill)
-  const int tile_lo = (wave / MS) * kTilesPerWave;
+  const int tile_lo = grp_index * kTilesPerWave;
 
   if constexpr (ST) {
-    constexpr int kDepth = 3;                        // k-steps of weights in flight: 3 x 12 MFMAs x 16 cycles ahead of their use
+    constexpr int kDepth = KD;                       // k-steps of weights in flight: KD x (G_TILES x MTW) MFMAs x 16 cycles ahead of their use
     bf16x8 wq[kDepth][MTW];
     if (n_layers >= 1) {                             // layer 1's first k-steps travel under conv0
 #pragma unroll
@@ -480,13 +555,51 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
     // a SIMD drift apart and one's epilogue runs under the other's MFMAs
     constexpr bool kBarrier = !(MS == 1 && kTilesPerWave % kTilesPerBoard == 0);
     if (kBarrier) __syncthreads();
+    C4_TSTAMP(2);
     for (int layer = 1; layer <= n_layers; layer++) {
       const bf16x8* wl = p.w + (size_t)(layer - 1) * G::kWFrags * 64;
       const bool has_next = layer < n_layers;
       const float* bl = p.bias + (size_t)layer * C;
       const bool second = (layer & 1) == 0;          // second conv of a block: T -> X, += residual; the last one stores the tower's output
+#if C4_TOWER_ALT_PRIO
+      // experiment: the older wavefront of a SIMD wins every arbitration and runs ahead (it finishes the tower at 74 of the
+      // launch's 108 us, tools/tower_phases.py); alternate who has priority, layer by layer
+      if (((layer ^ (__builtin_amdgcn_readfirstlane(wave) >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef C4_PHASE_STAMPS
+      auto st_stamp = [&](int q) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (layer <= 19) C4_TSTAMP(2 + 3 * (layer - 1) + q);
+      };
+#elif defined(C4_TOWER64_FENCE)
+      // experiment (round 5): the diagnostic build's stamps made the 64-channel tower FASTER; which part of a stamp does it?
+      //   1 = compiler fence only, 2 = + s_waitcnt lgkmcnt(0), 3 = + vmcnt(0) (what a stamp executes, minus the clock read)
+      auto st_stamp = [&](int q) __attribute__((always_inline)) {
+        if (C4_TOWER64_FENCE == 1) asm volatile("" ::: "memory");
+        if (C4_TOWER64_FENCE == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (C4_TOWER64_FENCE == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      };
+#else
+      NoStamp st_stamp;
+#endif
+      if constexpr (MS == 1) {   // one wavefront per SIMD, registers to spare: three compile-time copies of the layer (see kMode)
+        if (layer == n_layers)
+          tower_layer_stream<C, NB, kTilesPerWave, MTW, kDepth, decltype(wq), decltype(st_stamp)&, 2>(true, true, T, X, wq, wl, false, bl, tile_lo, m0, lane, p.out, board0, p.n_boards, st_stamp);
+        else if (second)
+          tower_layer_stream<C, NB, kTilesPerWave, MTW, kDepth, decltype(wq), decltype(st_stamp)&, 1>(true, false, T, X, wq, wl, true, bl, tile_lo, m0, lane, p.out, board0, p.n_boards, st_stamp);
+        else
+          tower_layer_stream<C, NB, kTilesPerWave, MTW, kDepth, decltype(wq), decltype(st_stamp)&, 0>(false, false, X, T, wq, wl, true, bl, tile_lo, m0, lane, p.out, board0, p.n_boards, st_stamp);
+      } else
       tower_layer_stream<C, NB, kTilesPerWave, MTW, kDepth>(second, layer == n_layers, second ? T : X, second ? X : T, wq, wl, has_next, bl, tile_lo, m0, lane,
-                                                            p.out, board0, p.n_boards);
+                                                            p.out, board0, p.n_boards, st_stamp);
+#ifdef C4_PHASE_STAMPS
+      if (layer == n_layers) {
+        st_stamp(3);
+        if (layer <= 19) tw_flush(2 + 3 * layer);
+        // lifetime of EVERY wavefront of the workgroup, by wavefront number (entry of the workgroup's first wavefront -> this one's exit)
+        if (lane == 0) atomicAdd(&c4_tower_clk[62 + wave], __builtin_amdgcn_s_memrealtime() - wave_t0);
+      }
+#endif
       if (layer == n_layers) return;
       if (kBarrier) {
         // Only the MS wavefronts that share cell tiles must meet between layers (each wrote its share of the output
@@ -495,11 +608,14 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
         // their once-per-layer epilogue at the same time with the matrix pipe idle.  Instead each group counts arrivals
         // in LDS: LDS operations of a wavefront execute in order, so whoever sees the count sees the stores before it.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        int* ctr = pair_ctr + wave / MS;
+        int* ctr = pair_ctr + grp_index;
         if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < MS * layer) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
+#if defined(C4_PHASE_STAMPS) || defined(C4_TOWER64_FENCE)
+      st_stamp(3);
+#endif
     }
   } else {
   // conv0: input image (T) -> X
@@ -555,10 +671,10 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
   C4_TL_END(1, p.out);
 }
 
-template <int C, int NB, int NT, int MS, bool ST = false>
+template <int C, int NB, int NT, int MS, bool ST = false, int KD = 3>
 int launch_tower(const TowerParams& p, uint32_t n_boards, hipStream_t stream, int device) {
   constexpr int kLds = Geo<C, NB>::kLdsBytes + (ST ? 64 : 0);   // + the wavefront pairs' hand-over counters
-  auto k = c4_conv_tower_kernel<C, NB, NT, MS, ST>;
+  auto k = c4_conv_tower_kernel<C, NB, NT, MS, ST, KD>;
   hipError_t e = c4host::opt_in_lds((const void*)k, kLds, device);
   if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: LDS opt-in (") + std::to_string(kLds) + " bytes) on device " + std::to_string(device) + ": " + hipGetErrorString(e));
   k<<<dim3((n_boards + NB - 1) / NB), dim3(NT), kLds, stream>>>(p.planes, p.w0, p.w, p.bias, p.out, p.n_boards, p.n_blocks);
@@ -573,12 +689,12 @@ int launch_tower(const TowerParams& p, uint32_t n_boards, hipStream_t stream, in
 // diagnostic build only: mean time per phase (us) of the 32-channel tower's workgroups since the last reset and the span from the
 // earliest entry to the latest exit (one launch)
 extern "C" int c4_debug_tower_phases(double* phase_us, int n, double* span_us, unsigned long long* n_workgroups, int reset) {
-  unsigned long long h[32];
+  unsigned long long h[80];
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(c4_tower_clk), sizeof h) != hipSuccess) return C4_ERR_HIP;
-  for (int i = 0; i < n && i < 24; i++) phase_us[i] = h[0] ? (double)h[1 + i] / (double)h[0] * 0.01 : 0.0;
-  if (span_us) *span_us = h[31] > h[30] ? (double)(h[31] - h[30]) * 0.01 : 0.0;
+  for (int i = 0; i < n && i < 76; i++) phase_us[i] = h[0] ? (double)h[1 + i] / (double)h[0] * 0.01 : 0.0;   // [61..68]: lifetime by wavefront number (64 channels)
+  if (span_us) *span_us = h[79] > h[78] ? (double)(h[79] - h[78]) * 0.01 : 0.0;
   if (n_workgroups) *n_workgroups = h[0];
-  if (reset) { unsigned long long z[32] = {0}; z[30] = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(c4_tower_clk), z, sizeof z) != hipSuccess) return C4_ERR_HIP; }
+  if (reset) { unsigned long long z[80] = {0}; z[78] = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(c4_tower_clk), z, sizeof z) != hipSuccess) return C4_ERR_HIP; }
   return C4_OK;
 }
 #endif
@@ -625,6 +741,10 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
 #endif
   if (channels == 32)
     return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);   // 8 waves: two per SIMD
+  // 64 channels, round 5: FOUR wavefronts, one per SIMD, each with all 64 output channels of two whole boards (no hand-over between
+  // layers at all) and a weight ring 6 / 3 k-steps deep in its 512 registers (config 2 / 3)
+  if (channels == 64 && config == 2) return launch_tower<64, 8, 256, 1, true, 6>(p, n_boards, (hipStream_t)stream, device);
+  if (channels == 64 && config == 3) return launch_tower<64, 8, 256, 1, true, 3>(p, n_boards, (hipStream_t)stream, device);
   return launch_tower<64, 8, 512, 2, true>(p, n_boards, (hipStream_t)stream, device);   // 8 wavefronts: pairs split the output channels; weights streamed
 }
 
