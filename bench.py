@@ -425,6 +425,7 @@ def main():
     ap.add_argument("--no-fused-step", action="store_true", help="A/B knob: output kernel and step kernel as two launches (round 3) instead of one")
     ap.add_argument("--pair-offset", type=int, default=1, help="A/B knob: capture_pair's offset_stage (session B starts when this stage of A's first round is done)")
     ap.add_argument("--tower-config", type=int, default=0, help="A/B knob: c4_conv_tower_bf16 workgroup shape (0 = automatic)")
+    ap.add_argument("--no-loader-waves", action="store_true", help="A/B knob: round 3's small-batch GEMM tiles (27 / 9 / 23 / 10) instead of their wave-specialised forms (41 / 42 / 44 / 43) up to 1 024 rows")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="internal: compute the cpu_baseline object alone and print it (the bench runs this leg in a child "
                          "process under a time limit, so that the checker can never cost the GPU line)")
@@ -477,6 +478,8 @@ def main():
     torch.manual_seed(1337)
     net = InferenceNet(ConnectFourNet(cfg), device, dtype=torch.bfloat16, gemm=args.gemm, gemm_config=args.gemm_config,
                        tower_config=args.tower_config)
+    if args.no_loader_waves:
+        net.use_loader_waves = False
 
     P = 1 if args.eager else max(1, min(args.sessions, G))
     R = max(1, args.rounds_per_step)

@@ -706,7 +706,12 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     // advantage is gone: same box, 11 for every layer 29.6-30.2 k games/s against 29.4-29.8 k, profiles/r04_gemm_configs.txt (4).)
     // ... and up to 1 024 rows, where a layer is a latency chain, the wave-specialised forms of round 3's small tiles (two or four
     // wavefronts that only issue the DMA pieces: 3-15 % less time alone, tools/gemm_small_ab.sh in profiles/r04_gemm_configs.txt)
-    config = m <= 384 ? 41 : m <= 640 ? (wide ? 42 : 41) : m <= 896 ? (wide ? 44 : 42) : m <= 1024 ? (wide ? 43 : 42) : 11;
+    // (Round 5, ADVICE r4: those forms were chosen with each GEMM ALONE; in the paired graph -- two sessions sharing the chip, 2 x 512 and
+    // 2 x 1 024 rows -- round 3's tiles without loader wavefronts are 5 % FASTER, 11 928 against 11 345 and 20 960 against 19 850 games/s,
+    // profiles/r05_small_rows_ab.txt: a 6- or 8-wavefront workgroup leaves no room beside the other session's output + step launch.  The
+    // automatic choice is therefore round 3's table again; a caller that has the chip to itself asks for 41 / 42 / 44 / 43 by number,
+    // c4a0_amd/nn.py latency_mode.)
+    config = m <= 384 ? 27 : m <= 640 ? (wide ? 9 : 27) : m <= 896 ? (wide ? 23 : 9) : m <= 1024 ? (wide ? 10 : 9) : 11;
     // The 64-channel net (K = 2 688, N = 5 376 / 2 688: four times the flops per layer): there the 256 x 192 tile
     // (64 x 96 per wavefront, 2-deep ring, 112 KB) pays -- BASELINE config 4 (2 x 2 048 rows) 862 -> 925-939 games/s,
     // config 5's per-GPU share (2 x 4 096 rows) 3 271 -> 3 671 (hipBLASLt: 911-919 / 3 736), profiles/r03_gemm_configs.txt

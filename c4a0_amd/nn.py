@@ -438,29 +438,32 @@ class InferenceNet:
         return lp.copy(), np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
 
     def _alone_config(self, m: int, n: int, k: int, latency: Optional[bool] = None) -> int:
-        """Tile configuration of a hidden layer when ONE session has the device to itself (latency_mode): above 1 024
-        rows the automatic choice is the fat tile that wins beside a second session's kernels; alone, up to 1 728 rows
-        the 96 x 96 tile (at most 2 x 256 workgroups, two per CU) and beyond that the 128 x 96 tile for the F-wide
-        layers are faster (c4_head_gemm.hip; every configuration computes the same bits).  0 = automatic."""
-        if not (self.latency_mode if latency is None else latency) or m <= 1024:
+        """Tile configuration of a hidden layer when ONE session has the device to itself (latency_mode).  Above 1 024 rows the
+        automatic choice is the fat tile that wins beside a second session's kernels; alone, up to 1 728 rows the 96 x 96 tile (at
+        most 2 x 256 workgroups, two per CU) and beyond that the 128 x 96 tile for the F-wide layers are faster.  Up to 1 024 rows the
+        wave-specialised forms of the small tiles (two or four wavefronts that only issue the DMA pieces) are 3-15 % faster ALONE and
+        5 % slower beside a second session (profiles/r04_gemm_configs.txt (3), profiles/r05_small_rows_ab.txt), so they too are asked
+        for here and nowhere else.  Every configuration computes the same bits.  0 = the library's automatic choice."""
+        if not (self.latency_mode if latency is None else latency):
             return 0
+        wide = n > k
         if k >= 2048:   # the 64-channel net: the automatic 256 x 192 tile for the 2F-wide layer, 128 x 192 for the F-wide ones
-            return 0 if n > k else 11   # (alone at 2 048 rows: 31 us against 49)
+            return 0 if (m <= 1024 or wide) else 11   # (alone at 2 048 rows: 31 us against 49)
+        if m <= 1024:
+            if not self.use_loader_waves:
+                return 0
+            return 41 if m <= 384 else ((42 if wide else 41) if m <= 640 else ((44 if wide else 42) if m <= 896 else (43 if wide else 42)))
         if m <= 1728:
-            return 44   # 96 x 96, four computing + four loading wavefronts (round 3: config 23, the same tile without loaders)
+            return 44 if self.use_loader_waves else 23   # 96 x 96, four computing (+ four loading) wavefronts
         # alone, the wave-specialised forms: 128 x 192 on 8 + 4 wavefronts for the 2F-wide layer, 128 x 96 on 4 + 2 for the F-wide ones
-        return 35 if n > k else 43
+        if self.use_loader_waves:
+            return 35 if wide else 43
+        return 11 if wide else 10
 
-    use_loader_waves = True   # False: round 3's tile table without the wave-specialised forms (A/B)
+    use_loader_waves = True   # False: no wave-specialised (loader-wavefront) forms anywhere (A/B)
 
     def _pick_config(self, m: int, n: int, k: int, latency: Optional[bool] = None) -> int:
-        cfg = self._alone_config(m, n, k, latency)
-        if self.use_loader_waves or k >= 2048:
-            return cfg
-        wide = n > k
-        if cfg == 0 and m <= 1024:      # c4_linear_bf16's automatic choice of round 3
-            return 27 if m <= 384 else ((9 if wide else 27) if m <= 640 else ((23 if wide else 9) if m <= 896 else (10 if wide else 9)))
-        return {44: 23, 35: 11, 43: 10}.get(cfg, cfg)
+        return self._alone_config(m, n, k, latency)
 
     def _linear_relu(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
                      latency: Optional[bool] = None) -> torch.Tensor:

@@ -308,22 +308,26 @@ def test_to_records_round_trip():
 
 
 def test_tile_choice_of_a_session_alone_on_the_device():
-    """InferenceNet._alone_config (host logic, no GPU): only a session that has the device to itself asks for the
-    small tiles, only between 1 025 and 1 728 rows for both layer widths (96 x 96, wave-specialised); beyond, the wave-specialised
-    128 x 96 tile for the F-wide layers and 128 x 192 tile for the 2F-wide layer (the automatic choice there, config 11 on eight
-    wavefronts, is the one that wins beside a second session); otherwise the automatic choice (0) stands."""
+    """InferenceNet._alone_config (host logic, no GPU): only a session that has the device to itself asks for tiles by number --
+    up to 1 024 rows the wave-specialised small tiles (41 / 42 / 44 / 43: faster alone, 5 % slower beside a second session, round 5),
+    between 1 025 and 1 728 rows the 96 x 96 tile with loader wavefronts, beyond that the wave-specialised 128 x 96 / 128 x 192 tiles;
+    otherwise the library's automatic choice (0) stands -- round 3's small tiles up to 1 024 rows, config 11 above."""
     from c4a0_amd.nn import InferenceNet
 
     net = object.__new__(InferenceNet)
     net.latency_mode = False
-    assert [net._alone_config(m, 2688, 1344) for m in (1, 1024, 1025, 1700, 4096)] == [0] * 5
+    assert [net._alone_config(m, 2688, 1344) for m in (1, 512, 1024, 1025, 1700, 4096)] == [0] * 6
+    assert net._alone_config(512, 1344, 1344, latency=True) == 41          # the per-call answer (forward_numpy) overrides the attribute
     net.latency_mode = True
-    assert net._alone_config(1024, 2688, 1344) == 0 and net._alone_config(1024, 1344, 1344) == 0
+    assert [net._alone_config(m, 2688, 1344) for m in (256, 512, 768, 1024)] == [41, 42, 44, 43]
+    assert [net._alone_config(m, 1344, 1344) for m in (256, 512, 768, 1024)] == [41, 41, 42, 42]
     assert net._alone_config(1025, 2688, 1344) == 44 and net._alone_config(1728, 1344, 1344) == 44
     assert net._alone_config(1729, 2688, 1344) == 35 and net._alone_config(1729, 1344, 1344) == 43
-    # the 64-channel net (k = 2 688): the automatic choice for the 2F-wide layer, the 128 x 192 tile for the F-wide ones
+    # the 64-channel net (k = 2 688): the automatic choice for the 2F-wide layer, the 128 x 192 tile for the F-wide ones above 1 024 rows
     assert net._alone_config(4096, 2688, 2688) == 11 and net._alone_config(1500, 2688, 2688) == 11
-    assert net._alone_config(4096, 5376, 2688) == 0 and net._alone_config(1500, 5376, 2688) == 0
+    assert net._alone_config(4096, 5376, 2688) == 0 and net._alone_config(1500, 5376, 2688) == 0 and net._alone_config(512, 2688, 2688) == 0
+    net.use_loader_waves = False                                            # the A/B switch: no loader-wavefront form anywhere
+    assert [net._alone_config(m, 2688, 1344) for m in (512, 1500, 4096)] == [0, 23, 11]
 
 
 def test_gemm_block_to_tile_map_is_a_bijection_for_every_grid():
