@@ -1085,10 +1085,20 @@ __global__ __launch_bounds__(256) void k_compact_move(Params p, const CompactPla
 // slots with room left return after one load.  Which block a node sits in changes nothing a game records.
 // ------------------------------------------------------------------------------------------
 constexpr int kReclaimThreads = 1024;
+constexpr uint32_t kReclaimSlotsPerGroup = 16;            // slots one workgroup looks at (a look is one 8-byte load; few slots ever need more)
+C4_DEV void reclaim_slot(const Params& p, uint32_t g, uint32_t min_free, uint32_t& s_tail);
 __global__ __launch_bounds__(kReclaimThreads) void k_arena_reclaim(Params p, uint32_t min_free) {
   __shared__ uint32_t s_tail;
-  const uint32_t g = blockIdx.x;
-  if (g >= p.n_slots) return;
+  // one workgroup per 16 slots, one after the other (the test is workgroup-uniform): a launch that finds nothing to do is ~100
+  // workgroups that return after 16 loads, not one 1 024-thread workgroup per slot
+  for (uint32_t k = 0; k < kReclaimSlotsPerGroup; k++) {
+    const uint32_t g = blockIdx.x * kReclaimSlotsPerGroup + k;
+    if (g >= p.n_slots) return;
+    reclaim_slot(p, g, min_free, s_tail);
+    __syncthreads();
+  }
+}
+C4_DEV void reclaim_slot(const Params& p, const uint32_t g, const uint32_t min_free, uint32_t& s_tail) {
   Slot* st = p.slots + g;
   const uint32_t state = st->state, arena = st->arena;
   if (slot_status(state) != kActive) return;
@@ -1485,7 +1495,8 @@ static int maybe_reclaim(c4_session* s) {
   if (cs != hipStreamCaptureStatusActive) id = 0;
   if (id != s->reclaim_capture_id) { s->reclaim_capture_id = id; s->reclaim_count = 0; }
   if (s->reclaim_count++ % s->reclaim_period != 0) return C4_OK;
-  hipLaunchKernelGGL(k_arena_reclaim, dim3(s->p.n_slots), dim3(kReclaimThreads), 0, s->stream, s->p, reclaim_min_free(s->reclaim_period, s->p.max_sims));
+  hipLaunchKernelGGL(k_arena_reclaim, dim3((s->p.n_slots + kReclaimSlotsPerGroup - 1) / kReclaimSlotsPerGroup), dim3(kReclaimThreads), 0, s->stream, s->p,
+                     reclaim_min_free(s->reclaim_period, s->p.max_sims));
   HIP_TRY(hipGetLastError());
   return C4_OK;
 }

@@ -132,7 +132,7 @@ def test_config4_4096_games_n800_hash_evaluator_structure_and_oracle_subset():
     assert ctr["games_done"] == n and ctr["error"] == 0 and ctr["samples"] == len(recs) == counts.sum()
     _check_structure(recs, counts, ids)
     assert ctr["sims"] / n > 7 * 300
-    sub = sorted(np.random.default_rng(4).choice(ids, 16, replace=False).tolist())
+    sub = sorted(np.random.default_rng(4).choice(ids, 128, replace=False).tolist())   # round 5: 128 games through the oracle (16 before)
     want, _ = O.self_play([(g, 0, 0) for g in sub], 64, n_iter, 6.6, 0.01, "hash", n_threads=8)
     assert _subset(recs, sub) == oracle_samples_by_game(want)
 
@@ -144,7 +144,7 @@ def test_config4_4096_games_n800_8x64_network_t3_replay():
 
     n, n_iter = 4096, 800
     ids = list(range(n))
-    log_slots = sorted(np.random.default_rng(44).choice(n, 12, replace=False).tolist())   # no refill: slot g plays game g
+    log_slots = sorted(np.random.default_rng(44).choice(n, 32, replace=False).tolist())   # no refill: slot g plays game g (round 5: 32 games replayed, 12 before)
     recs, counts, ctr, seq = _run_logged(_net(8, 64), ids, n, n_iter, log_slots)
     assert ctr["games_done"] == n and ctr["error"] == 0
     _check_structure(recs, counts, ids)
@@ -160,7 +160,7 @@ def test_config5_per_rank_8192_games_n200_8x64_network_plain_and_dirichlet(diric
 
     n, n_iter = 8192, 200
     ids = [3 + 8 * i for i in range(n)]
-    log_slots = sorted(np.random.default_rng(5).choice(n, 16, replace=False).tolist())
+    log_slots = sorted(np.random.default_rng(5).choice(n, 48, replace=False).tolist())   # round 5: 48 games replayed (16 before)
     recs, counts, ctr, seq = _run_logged(_net(8, 64), ids, n, n_iter, log_slots, dirichlet=dirichlet)
     assert ctr["games_done"] == n and ctr["error"] == 0
     _check_structure(recs, counts, ids)
@@ -205,7 +205,7 @@ def test_bench_configuration_graph_two_sessions_equals_eager_and_oracle():
     n, n_iter = 8192, 100
     net = _net(4, 32)
     ids = list(range(n))
-    log_slots = sorted(np.random.default_rng(2).choice(2048, 24, replace=False).tolist())   # first generation: slot g plays the session's game g
+    log_slots = sorted(np.random.default_rng(2).choice(2048, 96, replace=False).tolist())   # first generation: slot g plays the session's game g (round 5: 96 games replayed, 24 before)
     ids0, ids1 = ids[0::2], ids[1::2]
     recs0, counts0, ctr0, seq = _run_logged(net, ids0, 2048, n_iter, log_slots)
     assert ctr0["games_done"] == len(ids0) and ctr0["error"] == 0
