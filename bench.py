@@ -679,7 +679,7 @@ def main():
         fl = flops_per_leaf(cfg)
         mfma_busy, mfma_src = None, None   # counters under the evaluator: not re-measured here, read from the committed PMC summary
         try:
-            pmc_file = next(f for f in ("r04_evaluator_pmc.json", "r03_evaluator_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r05_evaluator_pmc.json", "r04_evaluator_pmc.json", "r03_evaluator_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             mfma_busy = pm["backends"]["hip0" if net.gemm == "hip" else "hipblaslt0"]["evaluator_mfma_busy_frac_of_chip_time_weighted"]
             mfma_src = (f"profiles/{pmc_file}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles), time-weighted over the tower, the three "
