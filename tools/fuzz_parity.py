@@ -107,10 +107,10 @@ def fused_job():
 
 while time.time() - t0 < budget:
     r = rng.random()
-    if r < 0.25:
+    if r < 0.25 and "FUZZ_TREE_ONLY" not in os.environ:
         callback_job()
         continue
-    if r < 0.45:
+    if r < 0.45 and "FUZZ_TREE_ONLY" not in os.environ:
         fused_job()
         continue
     n_games = rng.choice([1, 2, 3, 7, 8, 9, 17, 40, 100])
@@ -127,7 +127,7 @@ while time.time() - t0 < budget:
     reqs = [(g, 0, 0) for g in ids]
     # a third of the jobs on a RECLAIMED arena (C4_FLAG_RECLAIM) with halves near the smallest the library accepts and a look at the
     # arenas every 1-7 launches: the live subtree is copied into the other half several times per game
-    reclaim = rng.random() < 0.33
+    reclaim = rng.random() < float(os.environ.get("FUZZ_RECLAIM_SHARE", "0.33"))   # (FUZZ_RECLAIM_SHARE=1: every tree job on a reclaimed arena)
     rperiod = rng.choice([1, 1, 2, 3, 7])
     rkw = dict(reclaim=True, reclaim_period=rperiod, blocks_per_slot=2 * (n_iter + 10 + 2 * (4 * rperiod + 16) + rng.choice([0, 0, 1, 7, 50]))) if reclaim else {}
     s = DeviceSession(n_slots, n_iter, c_expl, c_ply, planes_dtype=rng.choice([torch.float32, torch.bfloat16]), one_sim_per_step=one_sim, **rkw)
