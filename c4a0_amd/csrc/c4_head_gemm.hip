@@ -580,6 +580,137 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void c4_head_gemm32_kernel(C4_G
   store_wave_tile<TM, TN>(acc, bias_v, p, tm0 + wm * (BM / WM), tn0 + wn * (BN / WN), li, lg);
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 5: the 256 x 192 tile on FOUR wavefronts, one per SIMD, 128 x 96 per wavefront, operands staged THROUGH REGISTERS.
+// For the 64-channel net (K = 2 688: BASELINE configs 4 / 5), whose rounds are CU-time-bound and whose GEMMs are 56 % of that time.
+// Why this shape: per 64-deep k-tile the 8-wavefront 256 x 192 kernel (64 x 96 per wavefront, config 7 / 48) moves 8 x 20 KB of
+// fragments out of LDS + 56 KB of DMA into it and takes ~2 600 cycles where its MFMAs need 1 536; with 128 x 96 per wavefront the
+// fragments are 4 x 28 KB -- and what killed round 4's 4-wavefront form (config 49: 3 400 cycles) was the ISSUE of its DMA: a
+// wavefront that issues its own 14 pieces per k-tile is held 60-185 cycles per piece (MI355X_MICROARCH.md, LDS-DMA issue
+// cost) in the same in-order stream as its 96 MFMAs.  A global_load_dwordx4 costs its issue slot only, and a wavefront with 512
+// registers has room for the k-tile in flight (14 x 4 registers): load k-tile kt + 2 into registers, store k-tile kt + 1 from
+// registers into the ring's other stage (ds_write_b128, the XOR swizzle on the LDS address), multiply k-tile kt out of this one.
+// One barrier per k-tile: in front of it every wavefront has finished reading the stage that is written next and its own
+// stores of the stage that is read next have landed.  Same LDS image, same fragment reads, same MFMA order per accumulator as
+// every other configuration: same bits.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 1) void c4_head_gemm4_kernel(C4_GEMM_ARGS) {
+  C4_GEMM_UNPACK();
+  constexpr int WM = 2, WN = 2;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;          // 8 x 6 output tiles of 16 x 16 per wavefront
+  constexpr int kStageBytes = (BM + BN) * BK * 2;              // 56 KB
+  constexpr int kChunks = (BM + BN) / 8;                       // 1 KB pieces (8 rows x 128 bytes) per k-tile
+  constexpr int L = kChunks / 4;                               // pieces per wavefront per k-tile
+  static_assert(kChunks % 4 == 0 && (BM / 8) % 4 == 0, "every wavefront moves whole shares of both operands");
+  constexpr int LX = (BM / 8) / 4;                             // a wavefront's pieces i < LX are X rows, the others W rows
+  extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int li = lane & 15, lg = lane >> 4;
+  int tm, tn;
+  tile_of_block(blockIdx.x, p.xcd_mask, p.xcd_shift, p.xn_log2, p.rm, p.rn, p.rn_magic, tm, tn);
+  const int tm0 = tm * BM, tn0 = tn * BN;
+
+  // piece i of this wavefront: rows 8 c .. 8 c + 7 of the X tile (c < BM / 8) or of the W tile; lane l moves the 16 bytes of
+  // row l >> 3, k-group l & 7, to LDS slot (l & 7) ^ (row & 7) of that row
+  uint32_t src_off[L], dst_off[L];
+  const int r8 = lane >> 3, slot = lane & 7;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    const bool is_x = i < LX;
+    const int c = is_x ? wave + 4 * i : wave + 4 * (i - LX);
+    const int row = c * 8 + r8;
+    if (is_x) {
+      int gr = tm0 + row;
+      gr = gr < (int)p.M ? gr : (int)p.M - 1;                  // rows past the end re-read the last one (never stored)
+      src_off[i] = (uint32_t)gr * p.ldx * 2u + (uint32_t)(slot * 16);
+      dst_off[i] = (uint32_t)row * 128u + (uint32_t)((slot ^ (row & 7)) * 16);
+    } else {
+      src_off[i] = (uint32_t)(tn0 + row) * p.K * 2u + (uint32_t)(slot * 16);
+      dst_off[i] = (uint32_t)(BM + row) * 128u + (uint32_t)((slot ^ (row & 7)) * 16);
+    }
+  }
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((p.M - 1) * p.ldx + p.K) * 2u), 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(p.N * p.K * 2u), 0x00020000);
+  const int KT = (int)p.K / BK;
+  u32x4 stg[L];                                                // the k-tile in flight between global memory and LDS
+  auto load_tile = [&](int kt) __attribute__((always_inline)) {
+    // past the last k-tile: bit 31 in the per-lane offset puts the request beyond num_records -> zeros without a memory access
+    const uint32_t tail = kt >= KT ? 0x80000000u : 0u;
+#pragma unroll
+    for (int i = 0; i < L; i++)
+      stg[i] = __builtin_amdgcn_raw_buffer_load_b128(i < LX ? x_rsrc : w_rsrc, (int)(src_off[i] | tail), kt * (BK * 2), 0);
+  };
+  auto store_tile = [&](int kt) __attribute__((always_inline)) {
+    uint8_t* st = lds + (kt & 1) * kStageBytes;
+#pragma unroll
+    for (int i = 0; i < L; i++) *reinterpret_cast<u32x4*>(st + dst_off[i]) = stg[i];
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; a++)
+#pragma unroll
+    for (int b = 0; b < TM; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t frag_off0 = (uint32_t)li * 128u + (uint32_t)(((0 + lg) ^ (li & 7)) * 16);
+  const uint32_t frag_off1 = (uint32_t)li * 128u + (uint32_t)(((4 + lg) ^ (li & 7)) * 16);
+  const uint32_t x_base = (uint32_t)(wm * (BM / WM)) * 128u;
+  const uint32_t w_base = (uint32_t)(BM + wn * (BN / WN)) * 128u;
+  f32x4 bias_v[TN];
+#pragma unroll
+  for (int a = 0; a < TN; a++) bias_v[a] = *reinterpret_cast<const f32x4*>(p.bias + tn0 + wn * (BN / WN) + a * 16 + 4 * lg);
+
+  load_tile(0);
+  store_tile(0);                                               // (waits for the loads: the one exposed round trip of the kernel)
+  load_tile(1);
+  bf16x8 afr[2][TN], bfr[2][TM];
+  for (int kt = 0; kt < KT; kt++) {
+    // my stores of k-tile kt have landed (and my fragment reads of k-tile kt - 1 are long consumed); then everybody's have
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const uint8_t* st = lds + (kt & 1) * kStageBytes;
+    auto rd_x = [&](int kk, int b) __attribute__((always_inline)) {
+      bfr[kk][b] = *reinterpret_cast<const bf16x8*>(st + x_base + (kk ? frag_off1 : frag_off0) + b * 2048);
+    };
+    auto rd_w = [&](int kk, int a) __attribute__((always_inline)) {
+      afr[kk][a] = *reinterpret_cast<const bf16x8*>(st + w_base + (kk ? frag_off1 : frag_off0) + a * 2048);
+    };
+    // first half's fragments leave first; the staging work of the NEXT k-tiles (14 ds_write_b128 of k-tile kt + 1 into the other
+    // stage, 14 global loads of k-tile kt + 2) is issued while they travel
+#pragma unroll
+    for (int b = 0; b < TM; b++) rd_x(0, b);
+#pragma unroll
+    for (int a = 0; a < TN; a++) rd_w(0, a);
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile(kt + 1);                                        // k-tile kt + 1 (in registers since the previous iteration) -> stage (kt + 1) & 1
+    load_tile(kt + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int kPerStep = (TN + TM + TN - 1) / TN;          // second-half reads issued behind each weight row's MFMAs
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+#pragma unroll
+      for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0][a], bfr[0][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int r = a * kPerStep; r < (a + 1) * kPerStep && r < TN + TM; r++) {
+        if (r < TM) rd_x(1, r); else rd_w(1, r - TM);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+#pragma unroll
+      for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][a], bfr[1][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < TN; a++) asm volatile("" ::"v"(bias_v[a]));   // see c4_head_gemm_kernel
+  store_wave_tile<TM, TN>(acc, bias_v, p, tm0 + wm * (BM / WM), tn0 + wn * (BN / WN), li, lg);
+}
+
 // Tile order: of the factorizations xm * xn = 8 that divide the tile grid, the one whose rectangle pulls the fewest
 // operand rows into an XCD's L2; none -> plain row-major order.
 inline uint32_t set_tile_order(GemmParams& p, uint32_t tiles_m, uint32_t tiles_n, uint32_t bm, uint32_t bn) {
@@ -773,6 +904,7 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     case 50: return launch_gemm32<128, 192, 2, 4, 4, 4>(p, st, device);   // 8 wavefronts (64 x 48), 4-deep ring of 32-deep k-tiles, 80 KB, <= 128 registers
     case 51: return launch_gemm32<128, 192, 2, 4, 3, 4>(p, st, device);   // ... 3-deep ring, 60 KB
     case 52: return launch_gemm32<128, 192, 2, 2, 4, 2>(p, st, device);   // 4 wavefronts (64 x 96), 4-deep ring, 80 KB, <= 256 registers
+    case 53: return launch_common<256, 192>(c4_head_gemm4_kernel<256, 192>, p, 256, 2 * (256 + 192) * BK * 2, st, device);   // round 5: 4 wavefronts (128 x 96 each), operands staged through registers, 2-deep ring, 112 KB
     default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
   }
 }
