@@ -425,6 +425,7 @@ def main():
     ap.add_argument("--no-fused-step", action="store_true", help="A/B knob: output kernel and step kernel as two launches (round 3) instead of one")
     ap.add_argument("--pair-offset", type=int, default=1, help="A/B knob: capture_pair's offset_stage (session B starts when this stage of A's first round is done)")
     ap.add_argument("--tower-config", type=int, default=0, help="A/B knob: c4_conv_tower_bf16 workgroup shape (0 = automatic)")
+    ap.add_argument("--stream-priorities", default="", help="A/B knob: HIP stream priorities of the sessions' streams, e.g. '-1,0' (lower = higher priority)")
     ap.add_argument("--no-loader-waves", action="store_true", help="A/B knob: round 3's small-batch GEMM tiles (27 / 9 / 23 / 10) instead of their wave-specialised forms (41 / 42 / 44 / 43) up to 1 024 rows")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="internal: compute the cpu_baseline object alone and print it (the bench runs this leg in a child "
@@ -504,7 +505,8 @@ def main():
             sp.set_eval_cache(args.eval_cache, args.eval_cache_sims)
         if args.dirichlet:
             sp.set_dirichlet(*[float(v) for v in args.dirichlet.split(",")])
-        st = torch.cuda.Stream(device=device) if P > 1 else torch.cuda.current_stream(device)
+        prio = [int(v) for v in args.stream_priorities.split(",")] if args.stream_priorities else []   # A/B knob
+        st = (torch.cuda.Stream(device=device, priority=prio[p % len(prio)]) if prio else torch.cuda.Stream(device=device)) if P > 1 else torch.cuda.current_stream(device)
         with torch.cuda.stream(st):
             sp.bind(st)
             sp.start()
