@@ -24,13 +24,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--games", type=int, default=4096)
     ap.add_argument("--preroll", type=int, default=2500)
+    ap.add_argument("--n", type=int, default=100, help="n_mcts_iterations (1400 = the reference's default job: deep trees)")
+    ap.add_argument("--blocks", type=int, default=4, help="residual blocks of the network (--with-nn)")
     ap.add_argument("--with-nn", action="store_true", help="run the real evaluator between launches (cold caches)")
     args = ap.parse_args()
     from c4a0_amd import _lib
     from c4a0_amd.session import DeviceSession
 
     dev = torch.device("cuda:0")
-    s = DeviceSession(args.games, 100, 6.6, 0.01, device=dev, planes_dtype=torch.bfloat16)
+    s = DeviceSession(args.games, args.n, 6.6, 0.01, device=dev, planes_dtype=torch.bfloat16)
     s.set_games([(i, 0, 0) for i in range(args.games * 8)])
     s.bind()
     s.start()
@@ -38,7 +40,7 @@ def main():
     if args.with_nn:
         from c4a0_amd.nn import ConnectFourNet, GraphedEvaluator, InferenceNet, ModelConfig
         torch.manual_seed(1337)
-        net = InferenceNet(ConnectFourNet(ModelConfig(4, 32, 4, 2)), dev)
+        net = InferenceNet(ConnectFourNet(ModelConfig(args.blocks, 32, 4, 2)), dev)
         ev = GraphedEvaluator(net, s.planes, s.logprobs, s.q)
     else:
         s.logprobs.fill_(1.0 / 7.0)
@@ -56,7 +58,7 @@ def main():
             acc_full.append(buf.reshape(-1, 16).astype(np.int64))
     st = np.stack(acc)  # [launch, wave, 9]
     t0 = st[:, :, 0].min(axis=1, keepdims=True)
-    print(f"games={args.games} with_nn={args.with_nn}; times in us (10 ns ticks), over {st.shape[0]} launches x {st.shape[1]} wavefronts")
+    print(f"games={args.games} n={args.n} with_nn={args.with_nn}; times in us (10 ns ticks), over {st.shape[0]} launches x {st.shape[1]} wavefronts")
     print(f"  wave start spread: median {np.median(st[:, :, 0] - t0) / 100:.2f}  max {np.max(st[:, :, 0] - t0) / 100:.2f}")
     for k, name in enumerate(NAMES):
         dt = (st[:, :, k + 1] - st[:, :, k]) / 100.0
