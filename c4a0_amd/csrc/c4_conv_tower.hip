@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include <string>
+#include <type_traits>
 
 #include "../../include/c4a0_hip.h"
 #include "c4_head_out.hpp"
@@ -253,6 +254,43 @@ __device__ __forceinline__ void tower_layer(const uint4* __restrict__ src, uint4
 // tile) are read from LDS under the MFMAs of k-step s; the accumulators of all G_TILES tiles live in registers and the
 // epilogue (bias already in, ReLU / residual / convert / store) runs once per layer.
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
+// Where a streamed layer's weight fragments come from.  NoFeed: each wavefront asks global memory (L1 / L2) for its own, kDepth
+// k-steps ahead.  RingFeed (round 5, the 8-wavefront 64-channel kernel): the WORKGROUP fetches every fragment once, by global -> LDS
+// DMA, into a ring of four stages of one tap each (KC k-steps x MT fragments = 8 KB at C = 64), FOUR taps ahead of its use; the
+// wavefronts read their MTW fragments of k-step s + 2 out of the ring under the MFMAs of k-step s.  Why: with the weights
+// requested from global memory three k-steps ahead -- all the register ring has room for -- a request has 576 cycles of the
+// wavefront's own MFMAs (~1 150 with its SIMD partner's) to come back, less than an L2 hit takes once 256 workgroups stream: the
+// k-loop ran at half the matrix pipe's rate (tools/tower_phases.py) and 4.6 MB of fragments per workgroup and launch went
+// through the CU's L1.  One workgroup barrier per tap replaces the wavefront pairs' hand-over between layers:
+//   top of stage t (tap t of the tower, counted across layers):  my DMA piece of stage t + 1 has landed, my LDS reads and
+//   stores so far are done | barrier | stage t's slot (whose fragments everybody read during stage t - 1) takes stage t + 4.
+struct NoFeed { static constexpr bool kRing = false; };
+template <int C>
+struct RingFeed {
+  static constexpr bool kRing = true;
+  static constexpr int kStageSlots = (C / 16) * (C / 32) * 64;     // 16-byte slots per stage: MT x KC fragments of 64 lanes
+  const uint4* ring;                                                // LDS, 4 stages
+  __amdgpu_buffer_rsrc_t rsrc;                                      // all residual layers' fragments, contiguous
+  int t, n_stages, wave, lane;
+  __device__ __forceinline__ void issue(int st) {                   // this wavefront's 1 KB piece of stage st (past the tower's end: zeros, no memory access)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ring + (st & 3) * kStageSlots + wave * 64), 16,
+                                             (int)((uint32_t)(lane * 16) | (st >= n_stages ? 0x80000000u : 0u)), st * (kStageSlots * 16) + wave * 1024, 0, 0);
+  }
+  // (Wavefronts 0-3 -- one per SIMD -- issuing two pieces each, so that a SIMD's other wavefront multiplies under the issue: 84.7 -> 86.8 us
+  // alone, 110-112 -> 114.6 at 2 048 boards.  Not the issue cost, then.)
+  __device__ __forceinline__ void stage_top() {
+    t += 1;
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");     // in flight behind stage t + 1: my pieces of stages t + 2, t + 3
+    __builtin_amdgcn_s_barrier();
+    issue(t + 4);
+  }
+  template <typename WQ, int MTW>
+  __device__ __forceinline__ void read(WQ& wq, int s, int kc, int m0) const {   // k-step `kc` of stage t + 1 -> wq[s % 2]
+    const uint4* st = ring + ((t + 1) & 3) * kStageSlots + lane;
+#pragma unroll
+    for (int m = 0; m < MTW; m++) wq[s % 2][m] = __builtin_bit_cast(bf16x8, st[((m0 + m) * (C / 32) + kc) * 64]);
+  }
+};
 // kMode (round 5): -1 = kSecond / kLast are run-time flags and the epilogue walks its items one by one (the 8-wavefront kernel: one
 // inlined copy of the layer, 253 registers); 0 / 1 / 2 = first conv of a block / second conv / the tower's last layer as
 // COMPILE-TIME variants whose epilogue requests every residual first and has no branch per item (the 4-wavefront kernel, which
@@ -264,19 +302,22 @@ __device__ __forceinline__ float tower_relu1(float v) {
   asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
   return r;
 }
-template <int C, int NB, int G_TILES, int MTW, int kDepth, typename WQ, typename Stamp = NoStamp, int kMode = -1>
+template <int C, int NB, int G_TILES, int MTW, int kDepth, typename WQ, typename Stamp = NoStamp, int kMode = -1, typename Feed = NoFeed>
 __device__ __forceinline__ void tower_layer_stream(const bool kSecond, const bool kLast, const uint4* __restrict__ src, uint4* __restrict__ dst, WQ& wq,
                                                    const bf16x8* __restrict__ w_layer, bool has_next, const float* __restrict__ bias,
                                                    int tile_lo, int m0, int lane, uint16_t* __restrict__ out = nullptr,
-                                                   uint32_t board0 = 0, uint32_t n_boards = 0, Stamp&& stamp = NoStamp{}) {
+                                                   uint32_t board0 = 0, uint32_t n_boards = 0, Stamp&& stamp = NoStamp{}, Feed&& feed = NoFeed{}) {
   using G = Geo<C, NB>;
+  using FeedT = typename std::remove_reference<Feed>::type;
   constexpr int kSteps = 9 * G::KC;
   static_assert(kSteps % kDepth == 0, "the weight ring keeps its phase from layer to layer");
+  static_assert(!FeedT::kRing || (kDepth == 2 && G::KC == 2), "the LDS ring is read one stage (= one tap = two k-steps) ahead");
   const int li = lane & 15, lg = lane >> 4;
 
   // this layer's fragment of k-step s (tap s / KC, channel half s % KC), output-channel tile m0 + m; s >= kSteps
   // continues into the next layer (same formula, kWFrags fragments further)
   auto request = [&](int s) __attribute__((always_inline)) {
+    if constexpr (FeedT::kRing) { feed.template read<WQ, MTW>(wq, s, s % G::KC, m0); return; }
     const int sl = s % kSteps;
     const bf16x8* wl = w_layer + (s >= kSteps ? G::kWFrags * 64 : 0);
 #pragma unroll
@@ -324,6 +365,7 @@ __device__ __forceinline__ void tower_layer_stream(const bool kSecond, const boo
     }
     return o;
   };
+  if constexpr (FeedT::kRing) feed.stage_top();                       // (also the hand-over from the previous layer: everybody's epilogue stores are done)
   read_row(0, 0);
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -332,7 +374,10 @@ __device__ __forceinline__ void tower_layer_stream(const bool kSecond, const boo
     if (r + 1 < 3) read_row(r + 1, (r + 1) & 1);                    // under this row's 6 KC k-steps
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int dc = 0; dc < 3; dc++)
+    for (int dc = 0; dc < 3; dc++) {
+      if constexpr (FeedT::kRing) {
+        if (3 * r + dc > 0) { feed.stage_top(); __builtin_amdgcn_sched_barrier(0); }
+      }
 #pragma unroll
       for (int kc = 0; kc < G::KC; kc++) {
         const int s = (3 * r + dc) * G::KC + kc;                    // k-steps in tap order, as tower_layer sums them
@@ -343,9 +388,10 @@ __device__ __forceinline__ void tower_layer_stream(const bool kSecond, const boo
           for (int m = 0; m < MTW; m++)
             acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % kDepth][m], __builtin_bit_cast(bf16x8, bfrag), acc[g][m], 0, 0, 0);
         }
-        if (s + kDepth < kSteps || has_next) request(s + kDepth);    // this ring slot is free again
+        if (FeedT::kRing || s + kDepth < kSteps || has_next) request(s + kDepth);    // this ring slot is free again (the LDS ring: past the tower's end it holds zeros)
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
   }
   stamp(1);                                                         // (diagnostic build) the k-loop is done
   if constexpr (kMode >= 0) {
@@ -431,7 +477,8 @@ __device__ __forceinline__ void dma_weights(const void* w, uint32_t bytes, uint4
 
 // ST (C = 64): the residual layers run as tower_layer_stream (weights streamed through a ring, k-steps outside).
 // KD (ST only): k-steps of weights in flight in the register ring.
-template <int C, int NB, int NT, int MS, bool ST = false, int KD = 3>
+// RG (ST, MS = 2, 8 wavefronts): the weights through the workgroup's LDS ring (RingFeed) instead of every wavefront's own global loads.
+template <int C, int NB, int NT, int MS, bool ST = false, int KD = 3, bool RG = false>
 __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __restrict__ a_planes, const bf16x8* __restrict__ a_w0, const bf16x8* __restrict__ a_w,
                                                              const float* __restrict__ a_bias, uint16_t* __restrict__ a_out, uint32_t a_n_boards, uint32_t a_n_blocks) {
   // flat scalar arguments (12 dwords): preloaded into SGPRs at wavefront launch (build.py: -amdgpu-kernarg-preload-count)
@@ -439,8 +486,12 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
   C4_TL_BEGIN();
 #ifdef C4_PHASE_STAMPS
   unsigned long long tw_ts[64];
+  const unsigned long long wave_c0 = __builtin_amdgcn_s_memtime();   // shader cycles against 100 MHz ticks: the clock this workgroup ran at
+  const unsigned long long wave_r0 = __builtin_amdgcn_s_memrealtime();
   auto tw_flush = [&](int last) {
     if (threadIdx.x == 0) {
+      atomicAdd(&c4_tower_clk[70], __builtin_amdgcn_s_memtime() - wave_c0);
+      atomicAdd(&c4_tower_clk[71], __builtin_amdgcn_s_memrealtime() - wave_r0);
       atomicAdd(&c4_tower_clk[0], 1ull);
       for (int i = 0; i < last; i++) atomicAdd(&c4_tower_clk[1 + i], tw_ts[i + 1] - tw_ts[i]);
       atomicMin(&c4_tower_clk[78], tw_ts[0]);
@@ -483,6 +534,13 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
 #pragma unroll
     for (int m = 0; m < MTW; m++) wf[k][m] = p.w0[(k * G::MT + m0 + m) * 64 + lane];
   const int n_layers = 2 * (int)p.n_blocks;
+  if constexpr (ST && RG) {   // the ring's first four stages: requested first, they land under the input staging and conv0
+    RingFeed<C> f0{reinterpret_cast<const uint4*>(lds_raw) + 2 * G::kBufSlots,
+                   __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(p.w), 0, (int)(2u * p.n_blocks * G::kWFrags * 1024u), 0x00020000), -1, 9 * n_layers,
+                   __builtin_amdgcn_readfirstlane(wave), lane};
+#pragma unroll
+    for (int st = 0; st < 4; st++) f0.issue(st);
+  }
   auto load_layer_weights = [&](int layer) __attribute__((always_inline)) {   // layer >= 1: [t][m][kc][lane]
     const bf16x8* wl = p.w + (size_t)(layer - 1) * G::kWFrags * 64;
 #pragma unroll
@@ -521,7 +579,7 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
   }
   for (int i = tid; i < 2 * G::kBufSlots; i += NT) X[i] = make_uint4(0, 0, 0, 0);
   int* pair_ctr = reinterpret_cast<int*>(lds_raw + G::kLdsBytes);   // ST only: one counter per MS-group of wavefronts
-  if (ST && tid < 16) pair_ctr[tid] = 0;
+  if (ST && !RG && tid < 16) pair_ctr[tid] = 0;   // (RG: no hand-over counters -- and the ring's first stage, already on its way, lives there)
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < kIn; j++) {
@@ -540,7 +598,37 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
   constexpr bool kFuseOut = (C == 32);             // C = 64 has no registers left for the global address arithmetic (it would spill)
   const int tile_lo = grp_index * kTilesPerWave;
 
-  if constexpr (ST) {
+  if constexpr (ST && RG) {
+    static_assert(NT == 512 && MS == 2 && C == 64, "one 1 KB DMA piece per wavefront and stage");
+    // LDS behind the two images: the ring (4 stages x 8 KB), then the residual layers' biases (the layers read them at their top;
+    // out of global memory that load would sit behind the DMA pieces in flight and wait for all of them)
+    const uint4* ring = T + G::kBufSlots;
+    float* bias_lds = reinterpret_cast<float*>(lds_raw + 2 * G::kBufSlots * 16 + 4 * RingFeed<C>::kStageSlots * 16);
+    RingFeed<C> feed{ring, __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(p.w), 0, (int)(2u * p.n_blocks * G::kWFrags * 1024u), 0x00020000),
+                     -1, 9 * n_layers, __builtin_amdgcn_readfirstlane(wave), lane};
+    // (the first four stages were requested at the kernel's top -- see below -- and have had conv0's time to land)
+    for (int i = tid; i < n_layers * C; i += NT) bias_lds[i] = p.bias[C + i];
+    bf16x8 wq[2][MTW];
+    tower_layer<C, NB, true, false, false, kTilesPerWave, MTW, false>(T, X, wf, p.bias, tile_lo, m0, lane, [&]() __attribute__((always_inline)) {});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // stage 0 is in the ring (everybody's piece), the biases are in LDS
+    feed.template read<decltype(wq), MTW>(wq, 0, 0, m0);   // t = -1: stage 0's two k-steps
+    feed.template read<decltype(wq), MTW>(wq, 1, 1, m0);
+    for (int layer = 1; layer <= n_layers; layer++) {
+      const bool second = (layer & 1) == 0;
+      const float* bl = bias_lds + (size_t)(layer - 1) * C;
+      // the three compile-time copies of the layer (kMode: every residual requested up front, no branch per item): with the register ring at two
+      // k-steps this kernel has the registers for them (252, no spill; the 8-wavefront kernel that streams from global memory spills: 201 us)
+      if (layer == n_layers)
+        tower_layer_stream<C, NB, kTilesPerWave, MTW, 2, decltype(wq), NoStamp, 2, RingFeed<C>&>(true, true, T, X, wq, nullptr, false, bl, tile_lo, m0, lane, p.out, board0, p.n_boards, NoStamp{}, feed);
+      else if (second)
+        tower_layer_stream<C, NB, kTilesPerWave, MTW, 2, decltype(wq), NoStamp, 1, RingFeed<C>&>(true, false, T, X, wq, nullptr, true, bl, tile_lo, m0, lane, p.out, board0, p.n_boards, NoStamp{}, feed);
+      else
+        tower_layer_stream<C, NB, kTilesPerWave, MTW, 2, decltype(wq), NoStamp, 0, RingFeed<C>&>(false, false, X, T, wq, nullptr, true, bl, tile_lo, m0, lane, p.out, board0, p.n_boards, NoStamp{}, feed);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS that was given away (the pieces past the tower's end are zero fills)
+    if (n_layers > 0) return;                          // (the last layer stored the tower's output; without residual blocks conv0's image is copied out below)
+  } else if constexpr (ST) {
     constexpr int kDepth = KD;                       // k-steps of weights in flight: KD x (G_TILES x MTW) MFMAs x 16 cycles ahead of their use
     bf16x8 wq[kDepth][MTW];
     if (n_layers >= 1) {                             // layer 1's first k-steps travel under conv0
@@ -671,11 +759,12 @@ __global__ __launch_bounds__(NT) void c4_conv_tower_kernel(const uint16_t* __res
   C4_TL_END(1, p.out);
 }
 
-template <int C, int NB, int NT, int MS, bool ST = false, int KD = 3>
+template <int C, int NB, int NT, int MS, bool ST = false, int KD = 3, bool RG = false>
 int launch_tower(const TowerParams& p, uint32_t n_boards, hipStream_t stream, int device) {
-  constexpr int kLds = Geo<C, NB>::kLdsBytes + (ST ? 64 : 0);   // + the wavefront pairs' hand-over counters
-  auto k = c4_conv_tower_kernel<C, NB, NT, MS, ST, KD>;
-  hipError_t e = c4host::opt_in_lds((const void*)k, kLds, device);
+  // + the wavefront pairs' hand-over counters; RG: + the weight ring (4 stages) and the residual layers' biases
+  const int kLds = Geo<C, NB>::kLdsBytes + (ST ? 64 : 0) + (RG ? 4 * RingFeed<C>::kStageSlots * 16 + 2 * (int)p.n_blocks * C * 4 : 0);
+  auto k = c4_conv_tower_kernel<C, NB, NT, MS, ST, KD, RG>;
+  hipError_t e = c4host::opt_in_lds((const void*)k, RG ? 160 * 1024 : kLds, device);   // (RG: the size depends on the number of layers; the opt-in is made once per kernel)
   if (e != hipSuccess) return c4host::fail(C4_ERR_HIP, std::string("c4_conv_tower_bf16: LDS opt-in (") + std::to_string(kLds) + " bytes) on device " + std::to_string(device) + ": " + hipGetErrorString(e));
   k<<<dim3((n_boards + NB - 1) / NB), dim3(NT), kLds, stream>>>(p.planes, p.w0, p.w, p.bias, p.out, p.n_boards, p.n_blocks);
   e = hipGetLastError();
@@ -721,7 +810,7 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   // config (what a workgroup owns, never a board's arithmetic): 0 = by size (below), 1 = 16 boards / 8 wavefronts,
   // 2 = 8 boards / 8 wavefronts, 3 = 16 boards / 12 wavefronts (27.3 vs 28.0 us alone at 2 048 boards, no difference
   // in the bench).  The 64-channel tower has one shape.
-  if (config > 3) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config must be 0 (automatic) .. 3");
+  if (config > 4) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config must be 0 (automatic) .. 4");
   if (channels == 32 && config == 1) return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32 && config == 2) return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32 && config == 3) return launch_tower<32, 16, 768, 1>(p, n_boards, (hipStream_t)stream, device);
@@ -745,6 +834,10 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   // layers at all) and a weight ring 6 / 3 k-steps deep in its 512 registers (config 2 / 3)
   if (channels == 64 && config == 2) return launch_tower<64, 8, 256, 1, true, 6>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 64 && config == 3) return launch_tower<64, 8, 256, 1, true, 3>(p, n_boards, (hipStream_t)stream, device);
+  // config 4 (round 5): the 8-wavefront kernel with the weights through an LDS ring, fetched once per workgroup four taps ahead
+  // (as long as the layers' biases fit behind it: up to 23 residual blocks)
+  if (channels == 64 && config == 4 && Geo<64, 8>::kLdsBytes + 64 + 4 * RingFeed<64>::kStageSlots * 16 + 2 * (int)n_blocks * 64 * 4 <= 160 * 1024)
+    return launch_tower<64, 8, 512, 2, true, 2, true>(p, n_boards, (hipStream_t)stream, device);
   return launch_tower<64, 8, 512, 2, true>(p, n_boards, (hipStream_t)stream, device);   // 8 wavefronts: pairs split the output channels; weights streamed
 }
 

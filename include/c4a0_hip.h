@@ -319,8 +319,8 @@ int c4_sample_move(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, con
  *   out_dev    bf16 [n_boards][42][channels]  (cell-major, channels last)
  * channels must be 32 or 64.  config: 0 = the workgroup shape chosen from n_boards; 32 channels: 1 / 2 / 3 = 16 boards, 8 boards,
  * 16 boards on 12 wavefronts; 64 channels: 2 / 3 = four wavefronts (one per SIMD, whole boards and all 64 output channels each)
- * with a weight ring 6 / 3 k-steps deep instead of the default eight wavefronts in channel-splitting pairs -- every shape
- * computes the same bits. */
+ * with a weight ring 6 / 3 k-steps deep instead of the default eight wavefronts in channel-splitting pairs, 4 = the eight wavefronts
+ * with the weights fetched once per workgroup into an LDS ring (a workgroup barrier per tap) -- every shape computes the same bits. */
 int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w_dev, const float* bias_dev,
                        uint32_t n_boards, uint32_t channels, uint32_t n_blocks, void* out_dev, uint32_t config, void* stream);
 

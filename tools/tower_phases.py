@@ -45,6 +45,8 @@ if ch == 64:
 else:
     names = ["entry->input staged", "conv0"] + [f"layer {i}" for i in range(1, 2 * blocks + 1)]
     print("  mean workgroup, us: " + "  ".join(f"{nm} {v:.2f}" for nm, v in zip(names, ph)) + f"  | sum {sum(ph[:len(names)]):.2f}")
+if ph[70] > 0:
+    print(f"  shader clock over a workgroup's life (its first wavefront; s_memtime / s_memrealtime): {ph[69] / ph[70] * 0.1:.2f} GHz")
 spans = []
 for _ in range(20):
     torch.cuda.synchronize(); net.tower(x); spans.append(read()[1])
