@@ -809,8 +809,8 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   TowerParams p{(const uint16_t*)planes_dev, (const bf16x8*)w0_dev, (const bf16x8*)w_dev, bias_dev, (uint16_t*)out_dev, n_boards, n_blocks};
   // config (what a workgroup owns, never a board's arithmetic): 0 = by size (below), 1 = 16 boards / 8 wavefronts,
   // 2 = 8 boards / 8 wavefronts, 3 = 16 boards / 12 wavefronts (27.3 vs 28.0 us alone at 2 048 boards, no difference
-  // in the bench).  The 64-channel tower has one shape.
-  if (config > 4) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config must be 0 (automatic) .. 4");
+  // in the bench).  64 channels: 2 / 3 / 4 below (1 = the default).
+  if (config > 4 || (channels == 32 && config == 4)) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config must be 0 (automatic) .. 3 (32 channels) / .. 4 (64 channels)");
   if (channels == 32 && config == 1) return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32 && config == 2) return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32 && config == 3) return launch_tower<32, 16, 768, 1>(p, n_boards, (hipStream_t)stream, device);
