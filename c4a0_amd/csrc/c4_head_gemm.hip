@@ -904,6 +904,12 @@ extern "C" int c4_linear_bf16(const void* x_dev, const void* w_dev, const float*
     case 50: return launch_gemm32<128, 192, 2, 4, 4, 4>(p, st, device);   // 8 wavefronts (64 x 48), 4-deep ring of 32-deep k-tiles, 80 KB, <= 128 registers
     case 51: return launch_gemm32<128, 192, 2, 4, 3, 4>(p, st, device);   // ... 3-deep ring, 60 KB
     case 52: return launch_gemm32<128, 192, 2, 2, 4, 2>(p, st, device);   // 4 wavefronts (64 x 96), 4-deep ring, 80 KB, <= 256 registers
+    case 54: return launch_gemm<96, 192, 2, 2, 3, 1, 4>(p, st, device);    // config 21 wave-specialised: 4 computing (48 x 96) + 4 loading wavefronts, 108 KB: 252 workgroups at 1 700 rows, 25 % fewer operand bytes per CU than 96 x 96
+    case 55: return launch_gemm<96, 192, 2, 4, 3, 1, 4>(p, st, device);    // ... 8 computing (48 x 48) + 4 loading wavefronts
+    case 56: return launch_gemm<192, 96, 2, 2, 3, 1, 4>(p, st, device);    // 192 x 96: 4 computing (96 x 48) + 4 loading wavefronts
+    case 57: return launch_gemm<192, 96, 4, 2, 3, 1, 4>(p, st, device);    // ... 8 computing (48 x 48) + 4 loading wavefronts
+    case 58: return launch_gemm<192, 96, 2, 2, 4, 1, 4>(p, st, device);    // ... 4 + 4, 4-deep ring (144 KB)
+    case 59: return launch_gemm<192, 96, 2, 2, 3, 1, 2>(p, st, device);    // ... 4 computing + 2 loading wavefronts
     case 53: return launch_common<256, 192>(c4_head_gemm4_kernel<256, 192>, p, 256, 2 * (256 + 192) * BK * 2, st, device);   // round 5: 4 wavefronts (128 x 96 each), operands staged through registers, 2-deep ring, 112 KB
     default: return c4host::fail(C4_ERR_BAD_ARG, "c4_linear_bf16: unknown config");
   }

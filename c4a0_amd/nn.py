@@ -454,6 +454,11 @@ class InferenceNet:
                 return 0
             return 41 if m <= 384 else ((42 if wide else 41) if m <= 640 else ((44 if wide else 42) if m <= 896 else (43 if wide else 42)))
         if m <= 1728:
+            if wide and self.use_loader_waves and self.wide_tiles_r5:
+                # the 2F-wide layer (round 5, profiles/r05_gemm_configs.txt (5)): 128 x 96 while its 9 x 28 tiles are one wave of workgroups
+                # (10.7-11.1 us against 14-15), then 192 x 96 with two loading wavefronts (<= 9 x 28 tiles up to 1 728 rows, a quarter
+                # fewer operand bytes per CU than 96 x 96: 13.5-15.2 us against 15-17.4)
+                return 43 if m <= 1152 else 59
             return 44 if self.use_loader_waves else 23   # 96 x 96, four computing (+ four loading) wavefronts
         # alone, the wave-specialised forms: 128 x 192 on 8 + 4 wavefronts for the 2F-wide layer, 128 x 96 on 4 + 2 for the F-wide ones
         if self.use_loader_waves:
@@ -461,6 +466,7 @@ class InferenceNet:
         return 11 if wide else 10
 
     use_loader_waves = True   # False: no wave-specialised (loader-wavefront) forms anywhere (A/B)
+    wide_tiles_r5 = True      # False: round 4's choice for the 2F-wide layer between 1 025 and 1 728 rows (A/B)
 
     def _pick_config(self, m: int, n: int, k: int, latency: Optional[bool] = None) -> int:
         return self._alone_config(m, n, k, latency)

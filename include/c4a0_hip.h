@@ -331,7 +331,7 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
  * index or `config`): the evaluator is a function of the position, as the reference's is (one forward per
  * unique position, self_play.rs:203-237).  n % 192 == 0, k % 64 == 0 (42 * C features, C a multiple of 32); n, k, ldx,
  * ldy < 65 536; ldx % 8 == 0, ldy % 8 == 0 and x_dev, y_dev 16-byte aligned (rows are moved 16 bytes at a time); each operand
- * below 2 GiB.  config 0 = automatic, 1..53 = a specific tile configuration (tools/gemm_probe.py; all compute the same bits). */
+ * below 2 GiB.  config 0 = automatic, 1..59 = a specific tile configuration (tools/gemm_probe.py; all compute the same bits). */
 int c4_linear_bf16(const void* x_dev, const void* w_dev, const float* bias_dev, void* y_dev, uint32_t m, uint32_t n,
                    uint32_t k, uint32_t ldx, uint32_t ldy, uint32_t relu, uint32_t config, void* stream);
 /* The block -> tile map c4_linear_bf16 launches with for an m x n output cut into bm x bn tiles (XCD-rectangle order), computed

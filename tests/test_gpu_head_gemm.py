@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = list(range(1, 54))   # 29-34: round-4 tiles, 35-45: wave-specialised forms (loading wavefronts), 46-47: staggered wavefront halves
+CONFIGS = list(range(1, 60))   # 29-34: round-4 tiles, 35-45: wave-specialised forms (loading wavefronts), 46-47: staggered wavefront halves
 
 
 def _linear(L, x, w, b32, relu=1, config=0, out=None):
