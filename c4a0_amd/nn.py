@@ -452,7 +452,11 @@ class InferenceNet:
         if m <= 1024:
             if not self.use_loader_waves:
                 return 0
-            return 41 if m <= 384 else ((42 if wide else 41) if m <= 640 else ((44 if wide else 42) if m <= 896 else (43 if wide else 42)))
+            # (thresholds = where a tile's grid stops being one wave of workgroups; re-probed in round 5 with every configuration,
+            # tools/gemm_sweep.py, profiles/r05_gemm_configs.txt (6))
+            if wide:
+                return 41 if m <= 384 else (42 if m <= 576 else (44 if m <= 864 else 43))
+            return 41 if m <= 512 else 42
         if m <= 1728:
             if wide and self.use_loader_waves and self.wide_tiles_r5:
                 # the 2F-wide layer (round 5, profiles/r05_gemm_configs.txt (5)): 128 x 96 while its 9 x 28 tiles are one wave of workgroups

@@ -310,7 +310,7 @@ def test_to_records_round_trip():
 def test_tile_choice_of_a_session_alone_on_the_device():
     """InferenceNet._alone_config (host logic, no GPU): only a session that has the device to itself asks for tiles by number --
     up to 1 024 rows the wave-specialised small tiles (41 / 42 / 44 / 43: faster alone, 5 % slower beside a second session, round 5),
-    between 1 025 and 1 728 rows the 96 x 96 tile with loader wavefronts, beyond that the wave-specialised 128 x 96 / 128 x 192 tiles;
+    between 1 025 and 1 728 rows the 96 x 96 tile with loader wavefronts (the 2F-wide layer: 128 x 96 / 192 x 96), beyond that the wave-specialised 128 x 96 / 128 x 192 tiles;
     otherwise the library's automatic choice (0) stands -- round 3's small tiles up to 1 024 rows, config 11 above."""
     from c4a0_amd.nn import InferenceNet
 
@@ -319,9 +319,15 @@ def test_tile_choice_of_a_session_alone_on_the_device():
     assert [net._alone_config(m, 2688, 1344) for m in (1, 512, 1024, 1025, 1700, 4096)] == [0] * 6
     assert net._alone_config(512, 1344, 1344, latency=True) == 41          # the per-call answer (forward_numpy) overrides the attribute
     net.latency_mode = True
-    assert [net._alone_config(m, 2688, 1344) for m in (256, 512, 768, 1024)] == [41, 42, 44, 43]
-    assert [net._alone_config(m, 1344, 1344) for m in (256, 512, 768, 1024)] == [41, 41, 42, 42]
-    assert net._alone_config(1025, 2688, 1344) == 44 and net._alone_config(1728, 1344, 1344) == 44
+    assert [net._alone_config(m, 2688, 1344) for m in (256, 384, 385, 576, 577, 864, 865, 1024)] == [41, 41, 42, 42, 44, 44, 43, 43]
+    assert [net._alone_config(m, 1344, 1344) for m in (256, 512, 513, 768, 1024)] == [41, 41, 42, 42, 42]
+    # 1 025 - 1 728 rows: the F-wide layers on 96 x 96 (4 + 4 wavefronts); the 2F-wide layer on 128 x 96 while 9 x 28 tiles are one wave of
+    # workgroups, then on 192 x 96 (round 5: a quarter fewer operand bytes per CU)
+    assert net._alone_config(1025, 1344, 1344) == 44 and net._alone_config(1728, 1344, 1344) == 44
+    assert [net._alone_config(m, 2688, 1344) for m in (1025, 1152, 1153, 1728)] == [43, 43, 59, 59]
+    net.wide_tiles_r5 = False
+    assert net._alone_config(1025, 2688, 1344) == 44 and net._alone_config(1728, 2688, 1344) == 44
+    net.wide_tiles_r5 = True
     assert net._alone_config(1729, 2688, 1344) == 35 and net._alone_config(1729, 1344, 1344) == 43
     # the 64-channel net (k = 2 688): the automatic choice for the 2F-wide layer, the 128 x 192 tile for the F-wide ones above 1 024 rows
     assert net._alone_config(4096, 2688, 2688) == 11 and net._alone_config(1500, 2688, 2688) == 11
