@@ -491,10 +491,11 @@ C4_DEV void timing_helper(const Params& p, uint32_t lane) {
 // on even / odd lanes), `t_start` = the wavefront's start stamp (timed launches).
 template <typename PlaneT, bool NOISE, bool CACHE>
 C4_DEV void step_body(const Params& p, const uint32_t wave_index, const uint32_t lane, const uint32_t n_slots, Slot* st, const uint4 hot,
-                      const float nn_logit, const float nn_q, const unsigned long long t_start) {
+                      const float nn_logit, const float nn_q, const unsigned long long t_start, const uint32_t g) {
+  // g = this lane group's game (>= n_slots: none).  The stand-alone kernels give a wavefront the 8 games 8 wave_index .. + 7; the fused
+  // output + step kernel may give it fewer (C4_OUT_STEP_GPW), its other lane groups idle.
   const uint32_t sub = lane & 7;
   const int gbase = (int)(lane & ~7u);
-  const uint32_t g = wave_index * 8 + (lane >> 3);
   uint32_t c_sims = 0, c_S = 0, c_K = 0, c_E = 0, c_moves = 0, c_done = 0, c_skipped = 0, c_samples = 0;   // this launch only
   uint32_t c_probes = 0, c_hits = 0;
   // header words to every lane of the group (lane 3: state, arena, root ref, rng word)
@@ -862,7 +863,7 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
   // `if (active)` below, i.e. behind the wait for the state line -- a second, serial memory round trip (plus the
   // scalar loads of the two pointers) at the head of every wavefront's chain (round 3, found in the ISA).
   __builtin_amdgcn_sched_barrier(0);
-  step_body<PlaneT, NOISE, CACHE>(p, wave_index, lane, a_n_slots, st, hot, nn_logit, nn_q, t_start);
+  step_body<PlaneT, NOISE, CACHE>(p, wave_index, lane, a_n_slots, st, hot, nn_logit, nn_q, t_start, g);
 }
 
 // c4_session_scatter_outputs + c4_session_step as ONE launch (callback mode, c4_session_step_gather): a game takes its evaluator
@@ -889,7 +890,7 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
     nn_logit = a_answers[(size_t)row * 9 + (sub < 7 ? sub : 6)];
     nn_q = a_answers[(size_t)row * 9 + 7 + (sub & 1)];
   }
-  step_body<PlaneT, NOISE, CACHE>(p, wave_index, lane, a_n_slots, st, hot, nn_logit, nn_q, t_start);
+  step_body<PlaneT, NOISE, CACHE>(p, wave_index, lane, a_n_slots, st, hot, nn_logit, nn_q, t_start, g);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -910,6 +911,14 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
 #else
 #define C4_OUT_STEP_ATTR
 #endif
+// C4_OUT_STEP_GPW: games per stepping wavefront -- 8 (wavefronts 0 and 1 step the workgroup's 16 games) or 4 (wavefronts 0-3 step four
+// games each, their other four lane groups idle).  A launch lasts as long as its slowest wavefront, and a wavefront runs the UNION of
+// its games' control flow (the deepest descent, a mover's temperature + sampling, a second simulation behind a terminal leaf, one
+// after the other): with half the games that union is shorter, and the workgroup's six wavefronts are there anyway.  Which
+// wavefront steps a game changes nothing the game records.  (Counter rows: two wavefronts add to one row, by atomics as before.)
+#ifndef C4_OUT_STEP_GPW
+#define C4_OUT_STEP_GPW 8
+#endif
 template <typename PlaneT>
 __global__ __launch_bounds__(64 * c4ho::kHeadWaves, 1) C4_OUT_STEP_ATTR void c4_out_step_kernel(
     const uint4* __restrict__ hp, const uint4* __restrict__ hv, const uint4* __restrict__ wp, const uint4* __restrict__ wv,
@@ -917,20 +926,23 @@ __global__ __launch_bounds__(64 * c4ho::kHeadWaves, 1) C4_OUT_STEP_ATTR void c4_
     Params p) {
   __shared__ c4ho::Shared sh;
   C4_TL_BEGIN();
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7;
-  const uint32_t wave_index = blockIdx.x * 2 + wave;                    // wavefronts 0 and 1: games 16 blockIdx.x + 8 wave + (lane >> 3)
-  const uint32_t g = wave_index * 8 + (lane >> 3);
+  constexpr uint32_t kGpw = C4_OUT_STEP_GPW, kStepWaves = 16 / kGpw;
+  static_assert(kGpw == 8 || kGpw == 4, "16 games per workgroup on two or four stepping wavefronts");
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7, grp = lane >> 3;
+  const uint32_t b = wave * kGpw + grp;                                 // the lane group's board among the workgroup's 16
+  const bool mine = wave < kStepWaves && grp < kGpw;
+  const uint32_t g = mine ? blockIdx.x * 16 + b : a_n_slots;            // (>= n_slots: this lane group steps nothing)
+  const uint32_t wave_index = blockIdx.x * 2 + wave / (kStepWaves / 2);  // the counters' row: as many rows as the stand-alone kernel has wavefronts
   const uint32_t gs = g < a_n_slots ? g : 0;
   Slot* st = a_slots + gs;
   uint4 hot = make_uint4(0, 0, 0, 0);
-  if (wave < 2) hot = reinterpret_cast<const uint4*>(st)[sub];          // in flight under the output layers
+  if (wave < kStepWaves) hot = reinterpret_cast<const uint4*>(st)[sub]; // in flight under the output layers
   c4ho::head_out_block<16>(sh, hp, hv, wp, wv, bp, bv, a_n_slots, f8, sp8, sv8, const_cast<float*>(p.logprobs), const_cast<float*>(p.q), blockIdx.x);
   __syncthreads();
-  if (wave >= 2 || wave_index >= p.n_waves) return;
-  const uint32_t b = wave * 8 + (lane >> 3);
-  const float nn_logit = sh.res[b][sub < 7 ? sub : 6];
-  const float nn_q = sh.res[b][7 + (sub & 1)];
-  step_body<PlaneT, false, false>(p, wave_index, lane, a_n_slots, st, hot, nn_logit, nn_q, 0ull);
+  if (wave >= kStepWaves || wave_index >= p.n_waves) return;
+  const float nn_logit = sh.res[b & 15][sub < 7 ? sub : 6];
+  const float nn_q = sh.res[b & 15][7 + (sub & 1)];
+  step_body<PlaneT, false, false>(p, wave_index, lane, a_n_slots, st, hot, nn_logit, nn_q, 0ull, g);
   C4_TL_END(3, a_slots);
 }
 
