@@ -74,6 +74,7 @@ SIGNATURES = {
     "c4_session_compact": (C.c_int, [_vp, C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
     "c4_session_start": (C.c_int, [_vp]),
     "c4_session_step": (C.c_int, [_vp]),
+    "c4_session_set_step_shape": (C.c_int, [_vp, C.c_uint32]),
     "c4_session_step_head_out": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "c4_session_set_timing": (C.c_int, [_vp, C.c_int]),
     "c4_session_counters": (C.c_int, [_vp, _P(Counters)]),

@@ -911,22 +911,21 @@ __global__ __launch_bounds__(64, (NOISE || CACHE) ? 1 : C4_STEP_WAVES) void c4_s
 #else
 #define C4_OUT_STEP_ATTR
 #endif
-// C4_OUT_STEP_GPW: games per stepping wavefront -- 8 (wavefronts 0 and 1 step the workgroup's 16 games) or 4 (wavefronts 0-3 step four
-// games each, their other four lane groups idle).  A launch lasts as long as its slowest wavefront, and a wavefront runs the UNION of
-// its games' control flow (the deepest descent, a mover's temperature + sampling, a second simulation behind a terminal leaf, one
-// after the other): with half the games that union is shorter, and the workgroup's six wavefronts are there anyway.  Which
-// wavefront steps a game changes nothing the game records.  (Counter rows: two wavefronts add to one row, by atomics as before.)
-#ifndef C4_OUT_STEP_GPW
-#define C4_OUT_STEP_GPW 8
-#endif
-template <typename PlaneT>
+// kGpw: games per stepping wavefront -- 8 (wavefronts 0 and 1 step the workgroup's 16 games) or 4 (wavefronts 0-3 step four games
+// each, their other four lane groups idle; c4_session_set_step_shape).  A wavefront runs the UNION of its games' control flow (the
+// deepest descent, a mover's temperature + sampling, a second simulation behind a terminal leaf, one after the other), and the
+// workgroup's six wavefronts are there anyway.  Measured (profiles/r05_out_step_gpw.txt): beside a second session's kernels
+// (BASELINE config 2, the paired graph) 4 is +0.5 % (six of six alternating pairs), for a session alone (the reference's default job)
+// -0.4 %: the paired driver asks for 4, everybody else gets 8.  Which wavefront steps a game changes nothing the game records.
+// (Counter rows: two wavefronts add to one row, by atomics as before.)
+template <typename PlaneT, uint32_t kGpw>
 __global__ __launch_bounds__(64 * c4ho::kHeadWaves, 1) C4_OUT_STEP_ATTR void c4_out_step_kernel(
     const uint4* __restrict__ hp, const uint4* __restrict__ hv, const uint4* __restrict__ wp, const uint4* __restrict__ wv,
     const float* __restrict__ bp, const float* __restrict__ bv, Slot* __restrict__ a_slots, uint32_t a_n_slots, uint32_t f8, uint32_t sp8, uint32_t sv8,
     Params p) {
   __shared__ c4ho::Shared sh;
   C4_TL_BEGIN();
-  constexpr uint32_t kGpw = C4_OUT_STEP_GPW, kStepWaves = 16 / kGpw;
+  constexpr uint32_t kStepWaves = 16 / kGpw;
   static_assert(kGpw == 8 || kGpw == 4, "16 games per workgroup on two or four stepping wavefronts");
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7, grp = lane >> 3;
   const uint32_t b = wave * kGpw + grp;                                 // the lane group's board among the workgroup's 16
@@ -1359,6 +1358,7 @@ struct c4_session {
   hipStream_t stream = nullptr;
   uint32_t lanes_per_game = 8;   // c4_step_kernel's mapping (a 4-lane variant was built and measured: tools/experiments/)
   uint32_t n_waves = 0;       // wavefronts a step launches now (shrinks with c4_session_compact)
+  uint32_t out_step_gpw = 8;  // games per stepping wavefront of the fused output + step launch (c4_session_set_step_shape)
   uint32_t n_waves_cap = 0;   // as created: size of the per-wavefront arrays
   uint32_t seq = 0;
   bool timing = true;
@@ -1871,9 +1871,22 @@ int c4_session_step_head_out(c4_session* s, const void* hidden_policy_dev, const
                        (const uint4*)w_policy_dev, (const uint4*)w_value_dev, b_policy_dev, b_value_dev, s->p.slots, s->p.n_slots, features / 8,
                        policy_row_stride / 8, value_row_stride / 8, s->p);
   };
-  if (s->cfg.planes_dtype == 0) launch(c4_out_step_kernel<float>); else launch(c4_out_step_kernel<uint16_t>);
+  if (s->out_step_gpw == 4) {
+    if (s->cfg.planes_dtype == 0) launch(c4_out_step_kernel<float, 4>); else launch(c4_out_step_kernel<uint16_t, 4>);
+  } else {
+    if (s->cfg.planes_dtype == 0) launch(c4_out_step_kernel<float, 8>); else launch(c4_out_step_kernel<uint16_t, 8>);
+  }
   HIP_TRY(hipGetLastError());
   return maybe_reclaim(s);
+}
+
+// Games per stepping wavefront of the fused output + step launch: 8 (default) or 4 (see c4_out_step_kernel).  A scheduling knob: the
+// games' records do not depend on it.
+int c4_session_set_step_shape(c4_session* s, uint32_t games_per_wavefront) {
+  if (!s) return fail(C4_ERR_BAD_ARG, "null session");
+  if (games_per_wavefront != 4 && games_per_wavefront != 8) return fail(C4_ERR_BAD_ARG, "c4_session_set_step_shape: games_per_wavefront must be 4 or 8");
+  s->out_step_gpw = games_per_wavefront;
+  return C4_OK;
 }
 
 int c4_session_set_timing(c4_session* s, int enable) {

@@ -132,6 +132,11 @@ class DeviceSession:
         check(self.L.c4_session_set_timing(self._h, 1 if enable else 0))
         self._timing = bool(enable)
 
+    def set_step_shape(self, games_per_wavefront: int):
+        """Games per stepping wavefront of the fused output + step launch: 8 (default) or 4 (c4_session_set_step_shape).  A
+        scheduling knob -- the records do not depend on it: 4 is 0.5 % faster beside a second session's kernels, 8 alone."""
+        check(self.L.c4_session_set_step_shape(self._h, int(games_per_wavefront)))
+
     def round(self, evaluator: DeviceEvaluator):
         """One lock-step round: evaluate the leaves, step every game.  With an evaluator that offers its hidden activations
         (c4a0_amd.nn.InferenceNet) and the session in its default configuration with per-launch timing off (every HIP-graph
@@ -355,6 +360,9 @@ class DeviceSession:
         return steps
 
 
+PAIRED_STEP_GAMES_PER_WAVEFRONT = 4   # (8: the A/B)
+
+
 def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cuda.Stream], evaluator, steps_per_graph: int = 32,
                  strict: bool = False, offset_stage: int = 1) -> "torch.cuda.CUDAGraph":
     """TWO sessions' rounds captured into ONE HIP graph with an explicit software pipeline between them.
@@ -381,6 +389,7 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
     dev = a.device
     for s in sessions:
         s.set_timing(False)
+        s.set_step_shape(PAIRED_STEP_GAMES_PER_WAVEFRONT)   # (profiles/r05_out_step_gpw.txt: +0.5 % beside the other session's kernels)
     # warm the evaluator up outside the capture, once per stream (library handles, lazy module loads)
     for s, st in zip(sessions, streams):
         side = torch.cuda.Stream(device=dev)

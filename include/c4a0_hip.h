@@ -201,6 +201,10 @@ int c4_session_step(c4_session* s);
 int c4_session_step_head_out(c4_session* s, const void* hidden_policy_dev, const void* hidden_value_dev, const void* w_policy_dev,
                              const void* w_value_dev, const float* b_policy_dev, const float* b_value_dev, uint32_t features,
                              uint32_t policy_row_stride, uint32_t value_row_stride);
+/* How the fused launch above shares a workgroup's 16 games among its wavefronts: 8 games per stepping wavefront (default) or 4.
+ * A scheduling knob -- the games' records do not depend on it: 4 is 0.5 % faster where a second session's kernels share the chip
+ * (the paired graph of c4a0_amd.session.capture_pair asks for it), 8 where the session is alone. */
+int c4_session_set_step_shape(c4_session* s, uint32_t games_per_wavefront);
 
 /* Per-launch device-clock timing of the step kernel (c4_counters.step_kernel_ns) needs a launch
  * sequence number in the kernel arguments, which a HIP-graph capture would freeze: switch it

@@ -55,6 +55,26 @@ def test_records_do_not_depend_on_layout_or_mode():
         assert _records(**kw) == ref, name
 
 
+def test_step_shape_is_a_scheduling_knob(monkeypatch):
+    """c4_session_set_step_shape: 4 or 8 games per stepping wavefront of the fused output + step launch (the paired graph asks for 4,
+    a session alone keeps 8) -- the records are the same bytes; other values are refused."""
+    from c4a0_amd import session as S
+    from c4a0_amd._lib import C4Error
+
+    net = _net()
+    monkeypatch.setattr(S, "PAIRED_STEP_GAMES_PER_WAVEFRONT", 4)
+    four = _records(evaluator=net, resident_games=700, concurrent_sessions=2, n=1500)
+    monkeypatch.setattr(S, "PAIRED_STEP_GAMES_PER_WAVEFRONT", 8)
+    eight = _records(evaluator=net, resident_games=700, concurrent_sessions=2, n=1500)
+    alone = _records(evaluator=net, resident_games=700, concurrent_sessions=1, n=1500)
+    assert four == eight == alone
+    s = S.DeviceSession(8, 4, 6.6, 0.01, device=torch.device("cuda:0"))
+    with pytest.raises(C4Error):
+        s.set_step_shape(5)
+    s.set_step_shape(4)
+    s.close()
+
+
 def test_numpy_callback_equals_device_mode():
     """The reference-compatible callback sees only the UNIQUE leaves of each step (a different batch
     size every step, float32 planes across PCIe): same records as device mode."""
