@@ -493,7 +493,7 @@ template <typename PlaneT, bool NOISE, bool CACHE>
 C4_DEV void step_body(const Params& p, const uint32_t wave_index, const uint32_t lane, const uint32_t n_slots, Slot* st, const uint4 hot,
                       const float nn_logit, const float nn_q, const unsigned long long t_start, const uint32_t g) {
   // g = this lane group's game (>= n_slots: none).  The stand-alone kernels give a wavefront the 8 games 8 wave_index .. + 7; the fused
-  // output + step kernel may give it fewer (C4_OUT_STEP_GPW), its other lane groups idle.
+  // output + step kernel may give it fewer (c4_session_set_step_shape), its other lane groups idle.
   const uint32_t sub = lane & 7;
   const int gbase = (int)(lane & ~7u);
   uint32_t c_sims = 0, c_S = 0, c_K = 0, c_E = 0, c_moves = 0, c_done = 0, c_skipped = 0, c_samples = 0;   // this launch only
