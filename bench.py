@@ -61,6 +61,55 @@ def step_kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def kernel_timeline(sess, stream, net, n_rounds: int = 300, batch: int = 100):
+    """Per-kernel launch durations of ONE session's round as the timed region launches it -- tower, the heads' hidden-layer GEMMs,
+    and the fused output + step kernel (DeviceSession.round with per-launch timing off) -- from HIP events recorded on the session's
+    stream at every launch boundary (InferenceNet.stage_hook marks them).  The rounds are queued behind a blocker (a few large
+    matmuls) in batches, so the host has enqueued a whole batch before the GPU reaches it and the kernels run back to back; the
+    other session is idle, which is also what rocprofv3's kernel trace measures (it serialises the queues).
+    Returns ([(label, total_ms, launches)] in launch order, rounds measured)."""
+    sess.set_timing(False)
+    blocker = torch.ones((8192, 8192), dtype=torch.bfloat16, device=sess.device)
+    totals, order = {}, []
+    prev_hook = net.stage_hook
+    done = 0
+    try:
+        while done < n_rounds:
+            evs = []
+            with torch.cuda.stream(stream):
+                for _ in range(16):
+                    torch.mm(blocker, blocker)              # ~2 ms each: the batch below is fully queued before it starts
+                for _ in range(batch):
+                    marks = []
+
+                    def hook(stage, marks=marks):
+                        e = torch.cuda.Event(enable_timing=True)
+                        e.record(stream)
+                        marks.append((stage, e))
+                    net.stage_hook = hook
+                    sess.round(net)
+                    end = torch.cuda.Event(enable_timing=True)
+                    end.record(stream)
+                    evs.append((marks, end))
+            stream.synchronize()
+            for marks, end in evs:
+                seq = marks + [(-1, end)]
+                for i in range(len(seq) - 1):
+                    # hook(0) precedes the tower's launch, hook(2) follows it, hook(1) follows the first hidden layer's, hook(3 + i) the
+                    # policy head's further layers'; what follows the last mark is the fused output + step launch (nn.py forward_hidden)
+                    st_a = seq[i][0]
+                    label = "tower" if st_a == 0 else "gemm_first_hidden" if st_a == 2 else "out_step" if i == len(seq) - 2 else "gemm_narrow"
+                    if label not in totals:
+                        totals[label] = [0.0, 0]
+                        order.append(label)
+                    totals[label][0] += seq[i][1].elapsed_time(seq[i + 1][1])
+                    totals[label][1] += 1
+            done += batch
+    finally:
+        net.stage_hook = prev_hook
+    return [(k, totals[k][0], totals[k][1]) for k in order], done
+
+
 def usable_cores() -> int:
     try:
         n = len(os.sched_getaffinity(0))
@@ -144,6 +193,8 @@ def whole_job(args, device, real_stdout):
     mode: process start-up is not job time) -- in the three ways a caller
     can use it: the unmodified numpy callback (training.py:179-189), the same call with a
     `DeviceCallback` wrapper, and `evaluator=`.  Not the headline: one JSON line of its own."""
+    import pickle
+
     import c4a0_amd
     from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
 
@@ -179,9 +230,19 @@ def whole_job(args, device, real_stdout):
         res = c4a0_amd.play_games(reqs, 2000, n_iter, 6.6, 0.01, stats=st, **kw)
         recs, _counts = res.to_records()
         dt = time.perf_counter() - t0
+        # what the reference's generation does next (src/c4a0/training.py:62-63): pickle.dump(games, f) = __getstate__ = to_cbor
+        t0 = time.perf_counter()
+        blob = pickle.dumps(res)
+        dt_dump = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        back = pickle.loads(blob)
+        dt_load = time.perf_counter() - t0
         ref = recs if ref is None else ref
         out[name] = {"games_per_s": n_games / dt, "sims_per_s": st["sims"] / dt, "seconds": dt, "steps": st["steps"],
                      "samples": int(len(recs)), "samples_identical_to_device_mode": bool(recs.tobytes() == ref.tobytes()),
+                     "pickle_seconds": dt_dump, "unpickle_seconds": dt_load, "pickle_bytes": len(blob),
+                     "pickle_round_trip_identical": bool(back.to_records()[0].tobytes() == recs.tobytes()),
+                     "games_per_s_play_plus_pickle": n_games / (dt + dt_dump),
                      "arena_reclaim_passes": st.get("reclaim_passes", 0), "arena_reclaim_blocks": st.get("reclaim_blocks", 0)}
         if "eval_cache_entries" in kw:
             out[name]["cache_hit_rate"] = st["eval_cache_hits"] / max(1, st["eval_cache_probes"])
@@ -190,6 +251,61 @@ def whole_job(args, device, real_stdout):
             "config": {"workload": f"src/c4a0/main.py:40-51 defaults: {n_games} games, n_mcts_iterations={n_iter}, max_nn_batch_size=2000, 1-block/32-ch ResNet (4 policy / 2 value layers) bf16"},
             **out}
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
+
+def product_legs(args, device, real_stdout):
+    """`--product-legs`: the PRODUCT loop under the driver's clock: whole `c4a0_amd.play_games(reqs, ...,
+    evaluator=net)` calls at BASELINE config 2's shape -- reqs in, PlayGamesResult out; session set-up, graph captures, completion
+    polling, the tail where finished slots idle, narrowing, the sample hand-over and the pickling the reference does next all
+    inside the clock -- where the headline replays captured graphs over an endless queue:
+      whole_call_10xG          40 960 games (10 x G, SURVEY 8d's own N for config 2), resident games chosen by the library
+      whole_call_10xG_4096     the same job on exactly 4 096 slots (config 2's "4 096 concurrent games") -- and its records must equal the first's
+      one_generation_4096      4 096 games on 4 096 slots: what each rank of BASELINE config 3 really runs (no refill: the whole job is tail)
+      eval_cache_10xG          EXTENSION (off by default, not the reference's algorithm: it evaluates every leaf and dedups inside a
+                               batch only, self_play.rs:203-208): leaves whose position the evaluator has already answered skip the
+                               evaluator row; records must equal the cache-off job's -- all of them are compared
+    each with the call's wall time split into set-up / capture / steady / tail / drain (stats["phases"])."""
+    import hashlib
+    import pickle
+
+    import c4a0_amd
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    torch.manual_seed(1337)
+    net = InferenceNet(ConnectFourNet(ModelConfig(4, 32, 4, 2)), device, dtype=torch.bfloat16)
+    G = 4096
+    reqs = [c4a0_amd.GameMetadata(i, 0, 0) for i in range(10 * G)]
+    c4a0_amd.play_games(reqs[:64], 4096, 20, 6.6, 0.01, evaluator=net)      # untimed: code objects, LDS opt-ins, allocator warm-up
+    c4a0_amd.play_games(reqs[:G], 4096, 10, 6.6, 0.01, evaluator=net)       # ... and the tree arena of the big shapes (kept by the library between sessions)
+
+    def call(n, **kw):
+        st = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = c4a0_amd.play_games(reqs[:n], 4096, 100, 6.6, 0.01, evaluator=net, stats=st, **kw)
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        blob = pickle.dumps(res)
+        dt_dump = time.perf_counter() - t0
+        recs, counts = res.to_records()
+        ph = st["phases"]
+        return recs, {"games": n, "resident_games": st["n_slots"], "seconds": dt, "games_per_s": n / dt, "sims_per_s": st["sims"] / dt, "rounds": st["steps"],
+                      "samples": int(len(recs)), "phases_s": {k: ph[k] for k in ("setup_s", "start_and_capture_s", "steady_s", "tail_s", "drain_s")},
+                      "tail_share_of_call": ph["tail_s"] / dt, "graph_captures": ph["graph_captures"], "rounds_until_all_started": ph["rounds_until_all_started"],
+                      "pickle_seconds": dt_dump, "pickle_bytes": len(blob), "games_per_s_play_plus_pickle": n / (dt + dt_dump),
+                      "records_sha256": hashlib.sha256(recs.tobytes()).hexdigest()[:16],
+                      **({"cache_hit_rate": st["eval_cache_hits"] / max(1, st["eval_cache_probes"])} if kw.get("eval_cache_entries") else {})}
+
+    out = {}
+    base, out["whole_call_10xG"] = call(10 * G)
+    again, out["whole_call_10xG_4096"] = call(10 * G, resident_games=G)
+    out["whole_call_10xG_4096"]["records_identical_to_whole_call_10xG"] = bool(again.tobytes() == base.tobytes())
+    _r, out["one_generation_4096"] = call(G, resident_games=G)
+    cached, out["eval_cache_10xG"] = call(10 * G, eval_cache_entries=1 << 24)
+    out["eval_cache_10xG"]["samples_identical"] = bool(cached.tobytes() == base.tobytes())
+    out["eval_cache_10xG"]["samples_compared"] = int(len(base))
+    out["eval_cache_10xG"]["note"] = "EXTENSION, off by default; not part of the headline"
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 def config1_leg(device):
@@ -292,7 +408,9 @@ def other_config_legs(args, sessions) -> dict:
         "config5_per_gpu": base + ["--blocks", "8", "--channels", "64", "--n-mcts", "200", "--games-per-gpu", "8192", "--steps", "3", "--warmup", "1"],
         "config5_per_gpu_dirichlet": base + ["--blocks", "8", "--channels", "64", "--n-mcts", "200", "--games-per-gpu", "8192", "--steps", "3", "--warmup", "1",
                                              "--dirichlet", "1.0,0.25"],
-        "reference_default_job": base + ["--whole-job", "--whole-job-modes", "device_mode,numpy_callback"],
+        "config2_eval_cache": base + ["--steps", "6", "--warmup", "1", "--eval-cache", str(1 << 23)],
+        "reference_default_job": base + ["--whole-job", "--whole-job-modes", "device_mode,numpy_callback,extension_eval_cache_device_mode"],
+        "product_loop": base + ["--product-legs"],
         "config1": base + ["--config1-only"],
     }
     res = {}
@@ -309,16 +427,22 @@ def other_config_legs(args, sessions) -> dict:
             if rc != 0 or not line:
                 raise RuntimeError(f"child exited with {rc}: {stderr[-300:]}")
             d = json.loads(line[-1])
-            if name == "config1":
+            if name in ("config1", "product_loop"):
                 res[name] = d
             elif name == "reference_default_job":
+                keys = ("games_per_s", "sims_per_s", "seconds", "steps", "samples", "pickle_seconds", "unpickle_seconds", "pickle_bytes", "pickle_round_trip_identical",
+                        "games_per_s_play_plus_pickle")
                 res[name] = {"workload": d["config"]["workload"],
-                             "device": {k: d["device_mode"][k] for k in ("games_per_s", "sims_per_s", "seconds", "steps", "samples")},
-                             "numpy_callback": {k: d["numpy_callback"][k] for k in ("games_per_s", "sims_per_s", "seconds", "steps", "samples", "samples_identical_to_device_mode")}}
+                             "device": {k: d["device_mode"][k] for k in keys},
+                             "numpy_callback": {k: d["numpy_callback"][k] for k in keys + ("samples_identical_to_device_mode",)},
+                             "extension_eval_cache_device": {k: d["extension_eval_cache_device_mode"][k] for k in keys + ("samples_identical_to_device_mode", "cache_hit_rate")}}
             else:
                 res[name] = {"workload": d["config"]["workload"], "games_per_s": d["value"], "sims_per_s": d["sims_per_s"], "ms_per_round": d["ms_per_round"],
                              "games_completed": d["games_completed"], "timed_rounds": d["steps"] * d["config"]["rounds_per_step"],
-                             "nn_tflops": d["nn"]["achieved"], "step_kernel_us": d["roofline"]["device_clock"]["avg_kernel_us"]}
+                             "nn_tflops": d["nn"]["achieved"], "step_kernel_us": d["roofline"]["step_alone"]["device_clock"]["avg_kernel_us"]}
+                if d.get("eval_cache"):
+                    res[name]["eval_cache"] = d["eval_cache"]
+                    res[name]["note"] = "EXTENSION (evaluation cache, off by default): steady state like the headline; sample identity is asserted by product_loop.eval_cache_10xG on a whole job"
             res[name]["leg_seconds"] = time.perf_counter() - t0
         except Exception as e:   # a leg never costs the headline
             res[name] = {"error": repr(e)[:400], "leg_seconds": time.perf_counter() - t0}
@@ -430,6 +554,7 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="internal: compute the cpu_baseline object alone and print it (the bench runs this leg in a child "
                          "process under a time limit, so that the checker can never cost the GPU line)")
+    ap.add_argument("--product-legs", action="store_true", help="internal: whole play_games calls at BASELINE config 2's shape (10 x G games; one generation; with the evaluation cache), own JSON line")
     ap.add_argument("--config1-only", action="store_true", help="internal: BASELINE config 1 (32 games, n = 10, 1-block net) on the host cores and on the GPU, own JSON line")
     ap.add_argument("--whole-job", action="store_true",
                     help="instead of the steady-state bench: the reference's default self-play job, whole, in callback and device modes (own JSON line)")
@@ -437,7 +562,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs for the other single-GPU shapes (BASELINE config 4, config 5's per-GPU share, the reference's default job) that the default N = 1 run attaches as `other_configs`")
     ap.add_argument("--other-configs-seconds", type=float, default=150.0, help="time limit of EACH other_configs leg (a child process)")
-    ap.add_argument("--other-configs-total-seconds", type=float, default=360.0, help="time limit of all other_configs legs TOGETHER (legs past it are skipped)")
+    ap.add_argument("--other-configs-total-seconds", type=float, default=480.0, help="time limit of all other_configs legs TOGETHER (legs past it are skipped)")
     ap.add_argument("--whole-job-games", type=int, default=1700)
     ap.add_argument("--whole-job-n-mcts", type=int, default=1400)
     args = ap.parse_args()
@@ -459,6 +584,8 @@ def main():
     device = torch.device("cuda", dev_index)
     if args.whole_job:
         return whole_job(args, device, real_stdout)
+    if args.product_legs:
+        return product_legs(args, device, real_stdout)
     if args.config1_only:
         os.write(real_stdout, (json.dumps(config1_leg(device)) + "\n").encode())
         return
@@ -486,7 +613,7 @@ def main():
     R = max(1, args.rounds_per_step)
     timed_rounds, warm_rounds = args.steps * R, args.warmup * R
     preroll = args.preroll if args.preroll >= 0 else int(2.0 * 15.0 * n_iter)  # ~2 game lengths of sims
-    total_steps = preroll + warm_rounds + timed_rounds + args.instrumented_steps + 64
+    total_steps = preroll + warm_rounds + timed_rounds + 2 * max(300, args.instrumented_steps) + 64
     sims_per_game_lo = 8 * n_iter  # generous lower bound on sims per game -> upper bound on games needed
     trips = (args.eval_cache_sims or 6) if args.eval_cache else 1   # the cache lets a game run several simulations per step
     n_games = int(G * (2 + trips * total_steps / sims_per_game_lo)) + G
@@ -606,10 +733,20 @@ def main():
     ci1 = sess.counters()
     if ci1["error"]:
         sys.exit(f"device error {ci1['error']} in slot {ci1['error_slot']}")
-    if any(sp.counters()["games_started"] >= sp.n_games for sp in sessions):
-        sys.exit("bench ran out of queued games; raise n_games")
     di = {k: ci1[k] - ci0[k] for k in ci1 if k not in ("error", "error_slot")}
     step_kernel_ms = sum(a_ev.elapsed_time(b_ev) for a_ev, b_ev in ev)
+    # ---- ... and the round AS THE TIMED REGION LAUNCHES IT (per-launch timing off: the heads' output layers and the step are one
+    # launch, c4_out_step_kernel), every launch of session 0 bracketed by HIP events on its stream
+    timeline, tl_rounds, dt_tl = None, 0, None
+    if net.path == "hip" and not args.eager and not args.no_fused_step and not args.eval_cache and not args.dirichlet and rank == 0:
+        ct0 = sess.counters()
+        timeline, tl_rounds = kernel_timeline(sess, st0, net, n_rounds=max(300, args.instrumented_steps))
+        ct1 = sess.counters()
+        if ct1["error"]:
+            sys.exit(f"device error {ct1['error']} in slot {ct1['error_slot']}")
+        dt_tl = {k: ct1[k] - ct0[k] for k in ct1 if k not in ("error", "error_slot")}
+    if any(sp.counters()["games_started"] >= sp.n_games for sp in sessions):
+        sys.exit("bench ran out of queued games; raise n_games")
 
     # ---- multi-GPU: the one exchange step of the path -- all-gather the finished samples (untimed
     # end-of-job step; its time is reported beside the throughput).  Exactly what
@@ -667,13 +804,14 @@ def main():
         # s_memrealtime stamps taken inside the kernel): what rocprofv3's kernel duration measures
         dev_s = di["step_kernel_ns"] / 1e9 / max(1, di["step_launches"])
         achieved_dev = ab["total"] / n_inst / max(dev_s, 1e-12) / 1e9
-        traffic, traffic_current = None, None
+        traffic, traffic_current, traffic_fused = None, None, None
         tpath = os.path.join(ROOT, "profiles", "step_kernel_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("hbm_bytes_per_launch")
-                # counters are collected in their own rocprofv3 --pmc passes (tools/profile/run_r04.sh), not in this run: say whether
+                traffic_fused = (tj.get("c4_out_step_kernel") or {}).get("hbm_bytes_per_launch")
+                # counters are collected in their own rocprofv3 --pmc passes (tools/profile/run_r06.sh), not in this run: say whether
                 # they were taken on the step kernel this library holds (hash of c4_session.hip + c4_device.hpp at collection time)
                 traffic_current = tj.get("step_kernel_source_hash") == step_kernel_source_hash()
             except Exception:
@@ -681,12 +819,53 @@ def main():
         fl = flops_per_leaf(cfg)
         mfma_busy, mfma_src = None, None   # counters under the evaluator: not re-measured here, read from the committed PMC summary
         try:
-            pmc_file = next(f for f in ("r05_evaluator_pmc.json", "r04_evaluator_pmc.json", "r03_evaluator_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r06_evaluator_pmc.json", "r05_evaluator_pmc.json", "r04_evaluator_pmc.json", "r03_evaluator_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             mfma_busy = pm["backends"]["hip0" if net.gemm == "hip" else "hipblaslt0"]["evaluator_mfma_busy_frac_of_chip_time_weighted"]
             mfma_src = (f"profiles/{pmc_file}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles), time-weighted over the tower, the three "
                         "hidden-layer GEMMs and the output kernel, each launch ALONE on the chip at 2 048 rows (rocprofv3 --pmc serialises kernels); "
                         "not re-measured in this run")
+        except Exception:
+            pass
+        # ---- the fused launch of the timed region and the evaluator's kernels, from the event-bracketed rounds above
+        rows = sess.rows
+        F = 42 * cfg.conv_filter_size
+        conv_flops = 2 * 42 * 9 * 2 * cfg.conv_filter_size + cfg.n_residual_blocks * 2 * (2 * 42 * 9 * cfg.conv_filter_size ** 2)
+        kernels, fused = {}, None
+        if timeline:
+            flops = {"tower": rows * conv_flops, "gemm_first_hidden": 2 * rows * F * 2 * F, "gemm_narrow": 2 * rows * F * F}
+            names = {"tower": "c4_conv_tower_kernel", "gemm_first_hidden": "c4_head_gemm_kernel (the merged 2F-wide first hidden layer of both heads)",
+                     "gemm_narrow": "c4_head_gemm_kernel (an F-wide hidden layer)", "out_step": "c4_out_step_kernel"}
+            ab_tl = algorithmic_bytes(dt_tl, 2)
+            for label, ms, launches in timeline:
+                us = ms * 1e3 / launches
+                k = {"kernel": names[label], "calls_per_round": launches / tl_rounds, "avg_us": us, "launches_measured": launches}
+                if label in flops:
+                    tf = flops[label] / (us * 1e-6) / 1e12
+                    k.update({"bound": "mfma", "flops_per_launch": flops[label], "achieved_tflops": tf, "frac_of_mfma_peak": tf / MFMA_BF16_PEAK_TFLOPS})
+                else:
+                    gbps = ab_tl["total"] / tl_rounds / (us * 1e-6) / 1e9
+                    k.update({"bound": "hbm", "algorithmic_bytes_per_launch": ab_tl["total"] / tl_rounds, "achieved_gbps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS})
+                    fused = k
+                kernels[label] = k
+            per_round_us = sum(ms for _l, ms, _n in timeline) * 1e3 / tl_rounds
+            kernels["sum_per_session_round_us"] = per_round_us
+            kernels["share_of_round"] = {label: ms * 1e3 / tl_rounds / per_round_us for label, ms, _n in timeline}
+            kernels["rows_per_launch"] = rows
+            kernels["method"] = (f"{tl_rounds} eager rounds of one session ({rows} rows) right after the timed region, a HIP event on its stream at every launch boundary, queued in batches "
+                                 "behind a blocker so that the GPU runs them back to back; the other session idle (rocprofv3's kernel trace serialises the two queues the same way: "
+                                 "profiles/r06_kernel_stats.csv holds its averages for the same kernels); an event-to-event interval includes the dispatch gap between two dependent launches")
+        issue = None   # the step kernel's issue-slot occupancy, from the committed counter summary (own rocprofv3 --pmc passes, tools/profile/run_r06.sh)
+        try:
+            pmc_step = next(f for f in ("r06_step_kernel_pmc.json", "r05_step_kernel_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pw = json.load(open(os.path.join(ROOT, "profiles", pmc_step)))["games_65536"]["per_wave"]
+            waves_per_simd = 4   # 127-128 VGPRs: four wavefronts share a SIMD
+            issue = {"issue_slots_taken": pw["SQ_ACTIVE_INST_ANY_per_wave"] * waves_per_simd / pw["SQ_WAVE_CYCLES_per_wave"],
+                     "valu_share_of_issue": pw["SQ_ACTIVE_INST_VALU_per_wave"] / pw["SQ_ACTIVE_INST_ANY_per_wave"],
+                     "insts_per_wavefront": {k: pw[f"SQ_INSTS_{k}_per_wave"] for k in ("VALU", "SALU", "LDS", "VMEM_RD", "VMEM_WR")},
+                     "waves_per_simd": waves_per_simd, "at_games_per_launch": 65536,
+                     "formula": "SQ_ACTIVE_INST_ANY x wavefronts per SIMD / SQ_WAVE_CYCLES (both in quad-cycles per wavefront): the share of a SIMD's issue cycles in which one of its wavefronts issues",
+                     "source": f"profiles/{pmc_step} (rocprofv3 --pmc, own passes; stand-alone c4_step_kernel = the step_body the fused launch runs); not re-measured in this run"}
         except Exception:
             pass
         shape = (G, n_iter, cfg.n_residual_blocks, cfg.conv_filter_size)
@@ -724,27 +903,40 @@ def main():
                             "note": "EXTENSION switched on by --eval-cache: repeated positions skip the evaluator; not the headline configuration"}
                            if args.eval_cache else None),
             "sims_per_game": sims / max(1.0, games),
-            "roofline": {"bound": "hbm", "kernel": "c4_step_kernel (expand+backup+move+select+encode, fused)",
-                         "measured_on": "the instrumented launches after the timed region (stand-alone c4_step_kernel, per-launch timing on); inside the "
-                                        "timed region the same step_body runs as the second half of c4_out_step_kernel, behind the heads' output layers",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic,
-                         "traffic_source": "profiles/step_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, corrected per MI355X_MICROARCH.md); not re-measured in this run",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("c4_out_step_kernel: the launch of the timed region -- the heads' output layers, then expand + backup + move + select + encode of the same games"
+                                    if fused else "c4_step_kernel (expand+backup+move+select+encode, fused)"),
+                         "measured_on": ("the event-bracketed rounds right after the timed region (see kernels.method); `achieved` = SURVEY 8(d)'s tree bytes (92 S + 28 K + 332 E + encode, "
+                                         "device-counted) per launch / this launch's average duration -- the output layers' own operands (head_out_operand_bytes_per_launch) are not counted"
+                                         if fused else "the instrumented stand-alone launches after the timed region"),
+                         "achieved": fused["achieved_gbps"] if fused else achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (fused["achieved_gbps"] if fused else achieved) / HBM_PEAK_GBPS,
+                         "avg_launch_us": fused["avg_us"] if fused else avg_kernel_s * 1e6,
+                         "launches_measured": fused["launches_measured"] if fused else n_inst, "games_per_launch": sess.rows,
+                         "algorithmic_bytes_per_launch": fused["algorithmic_bytes_per_launch"] if fused else ab["total"] / n_inst,
+                         "head_out_operand_bytes_per_launch": (rows * 2 * F * 2 + 9 * F * 2 + rows * 36) if fused else None,
+                         "traffic": traffic_fused if fused else traffic,
+                         "traffic_source": "profiles/step_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, each in its own run, corrected per MI355X_MICROARCH.md); not re-measured in this run",
                          "traffic_collected_on_this_step_kernel": traffic_current,
-                         # the memory system's ceiling for THIS access pattern (random whole 128-byte lines from an HBM-resident table,
-                         # tools/gather_lab.hip): 6.7 TB/s, i.e. 84 % of the 8 TB/s the fraction above is quoted against
-                         "frac_of_practical_ceiling": achieved / 6700.0,
-                         "device_clock_frac_of_practical_ceiling": achieved_dev / 6700.0,
-                         "avg_launch_us": avg_kernel_s * 1e6,
-                         "device_clock": {"avg_kernel_us": dev_s * 1e6, "achieved": achieved_dev, "frac": achieved_dev / HBM_PEAK_GBPS,
-                                          "note": "in-kernel s_memrealtime stamps; the HIP-event bracket adds the dispatch and completion latency of one launch"},
+                         # what binds it: not bytes.  At every launch size the SIMDs' issue slots are what is full (VALU above all), see DESIGN.md 4.2
+                         "binding_roof": "valu_issue", "issue_slot_occupancy": issue,
+                         "step_alone": {
+                             "kernel": "c4_step_kernel (the same step_body as a launch of its own: per-launch device-clock timing needs it; what the callback mode and eager sessions run)",
+                             "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                             # the memory system's ceiling for THIS access pattern (random whole 128-byte lines from an HBM-resident table,
+                             # tools/gather_lab.hip): 6.7 TB/s, i.e. 84 % of the 8 TB/s the fraction above is quoted against
+                             "frac_of_practical_ceiling": achieved / 6700.0,
+                             "device_clock_frac_of_practical_ceiling": achieved_dev / 6700.0,
+                             "avg_launch_us": avg_kernel_s * 1e6,
+                             "device_clock": {"avg_kernel_us": dev_s * 1e6, "achieved": achieved_dev, "frac": achieved_dev / HBM_PEAK_GBPS,
+                                              "note": "in-kernel s_memrealtime stamps; the HIP-event bracket adds the dispatch and completion latency of one launch"},
+                             "launches_measured": n_inst, "algorithmic_bytes_per_launch": ab["total"] / n_inst},
                          "practical_ceilings": {"random_128B_lines_from_HBM_GBps": 6700, "dependent_line_chain_ns_per_level_idle": 550,
                                                 "source": "profiles/r02_gather_lab.jsonl (tools/gather_lab.hip on MI355X): what the memory system gives the tree walk's access pattern; at this launch size the kernel is bound by one wavefront's dependent chain, not by bytes (DESIGN.md 4.2)"},
-                         "launches_measured": n_inst, "games_per_launch": sess.n_slots,
-                         "algorithmic_bytes_per_launch": ab["total"] / n_inst,
                          "bytes_per_sim": {k: v / max(1, di["sims"]) for k, v in ab.items()},
                          "S_per_sim": di["select_levels"] / max(1, di["sims"]), "K_per_sim": di["backup_nodes"] / max(1, di["sims"]),
-                         "E_per_sim": di["expansions"] / max(1, di["sims"])},
+                         "E_per_sim": di["expansions"] / max(1, di["sims"]),
+                         "kernels": kernels or None},
             "nn": {"bound": "mfma", "flops_per_leaf": fl, "achieved": fl * G * timed_rounds / elapsed / 1e12,
                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": fl * G * timed_rounds / elapsed / 1e12 / MFMA_BF16_PEAK_TFLOPS,

@@ -21,7 +21,8 @@ FLAG_ONE_SIM_PER_STEP = 2
 FLAG_RECLAIM = 4          # include/c4a0_hip.h C4_FLAG_RECLAIM: the tree arena is reclaimed while a game is played
 FLAG_NO_RECLAIM = 8       # ... never, also where the default sizing would
 MAX_SAMPLES_PER_GAME = 43
-ABI_VERSION = 7   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
+ABI_VERSION = 8   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
+STRUCT_LAYOUT_SINCE = 7   # the ABI version that last changed a structure's layout (c4_config.reclaim_period, c4_counters.reclaim_*)
 
 
 class C4Error(RuntimeError):
@@ -88,6 +89,9 @@ SIGNATURES = {
     "c4_session_root_stats": (C.c_int, [_vp, C.c_uint32, _P(C.c_float), _P(C.c_float), _P(C.c_float),
                                         _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint64)]),
     "c4_trim_cached_memory": (C.c_int, []),
+    "c4_records_to_cbor": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, _P(C.c_uint64)]),
+    "c4_shuffle_games": (C.c_int, [C.c_uint64, C.c_uint64, _vp]),
+    "c4_cbor_to_records": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _vp, C.c_uint64, _P(C.c_uint64), _P(C.c_uint64)]),
     "c4_session_leaf_keys": (C.c_int, [_vp, _vp]),
     "c4_session_unique_leaves": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "c4_session_scatter_outputs": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
@@ -138,6 +142,12 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         if L.c4_abi_version() != ABI_VERSION and not diagnostic:
             raise ImportError(f"{LIB_PATH} implements C ABI version {L.c4_abi_version()}, this binding is written for {ABI_VERSION}")
+        if diagnostic and L.c4_abi_version() < STRUCT_LAYOUT_SINCE:
+            # an A/B library may lack newer entry points, but the structures this binding hands it (Config) and reads back (Counters:
+            # error / error_slot sit behind the counters) must be the ones it was compiled with -- an older layout would report a failed
+            # run as a clean one
+            raise ImportError(f"{LIB_PATH} implements C ABI version {L.c4_abi_version()}: c4_config / c4_counters changed layout in version "
+                              f"{STRUCT_LAYOUT_SINCE}; build the A/B library from a revision at or after it")
         # a library compiled from other sources than the ones beside it is refused, not used
         # (C4A0_HIP_LIB names a diagnostic build with its own flags: not compared)
         if "C4A0_HIP_LIB" not in os.environ:

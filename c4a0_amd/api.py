@@ -22,10 +22,29 @@ import torch
 from .results import GameMetadata, PlayGamesResult, results_from_records
 from .session import DeviceEvaluator, DeviceSession
 
-# Games advanced in lock-step per step.  Measured on MI355X (4x32 network): 16 384 games as ONE resident
-# batch take 2.3 s (the step count is set by the longest game, most slots idle at the end), the same
-# games through 4 096 slots that are refilled as games finish take well under half of that.
+# Games advanced in lock-step per round when the caller does not say (`resident_games=`).  Two forces (MI355X, BASELINE config 2's
+# network, a 40 960-game job, profiles/r06_whole_call.txt): more resident games make a round more efficient -- 37.6 / 41.6 / 43.9 k
+# game-rounds per ms at 4 096 / 8 192 / 16 384 slots (fuller GEMM grids, a step kernel further from its latency floor) -- but the
+# job's TAIL, the rounds after the last request has been started, when finished slots stay empty, grows with them: 0.24 / 0.34 /
+# 0.53 s; with every game resident at once the whole job is tail (1.8 s against 1.57).  A quarter of the job, between 4 096 and
+# 16 384 slots, sits in the flat optimum; the tree arenas of the slots are kept below a quarter of the device's free memory.
 DEFAULT_RESIDENT_GAMES = 4096
+MAX_DEFAULT_RESIDENT_GAMES = 16384
+
+
+def default_resident_games(n_games: int, n_mcts_iterations: int, graph_safe: bool, device=None) -> int:
+    if n_games <= DEFAULT_RESIDENT_GAMES or not graph_safe:   # callback / multi-model modes: a host round trip per round, rows are not the limit
+        return min(n_games, DEFAULT_RESIDENT_GAMES)
+    want = min(MAX_DEFAULT_RESIDENT_GAMES, max(DEFAULT_RESIDENT_GAMES, -(-n_games // 4 // 1024) * 1024))
+    # arena bytes per slot (include/c4a0_hip.h c4_config.blocks_per_slot): 43 n + 8 blocks of 128 bytes, or two reclaimed halves above n = 1 000
+    n = max(1, n_mcts_iterations)
+    per_slot = 128 * ((43 * n + 8) if n <= 1000 else 2 * (5 * n // 2 + 554))
+    try:
+        free, _total = torch.cuda.mem_get_info(device)
+        want = min(want, max(DEFAULT_RESIDENT_GAMES, int(free // 4 // per_slot) // 1024 * 1024))
+    except Exception:
+        pass
+    return want
 
 
 def _planes_from_bits(mask: np.ndarray, value: np.ndarray) -> np.ndarray:
@@ -158,19 +177,25 @@ class _MultiModelEvaluator:
         return lp_out, q_out
 
 
-def _validate(reqs, max_nn_batch_size, n_mcts_iterations, py_eval_pos_cb, evaluator):
-    for r in reqs:
-        if not all(hasattr(r, a) for a in ("game_id", "player0_id", "player1_id")):
-            raise TypeError("reqs must be a sequence of GameMetadata")  # reference: extract() fails, pybridge.rs:30
+def _ids_of(reqs) -> np.ndarray:
+    """uint64[n, 3] (game_id, player0_id, player1_id) of the requests: the one pass over the caller's objects."""
+    try:
+        return np.array([(r.game_id, r.player0_id, r.player1_id) for r in reqs], dtype=np.uint64).reshape(-1, 3)
+    except AttributeError:
+        raise TypeError("reqs must be a sequence of GameMetadata") from None   # reference: extract() fails, pybridge.rs:30
+
+
+def _validate(reqs, max_nn_batch_size, n_mcts_iterations, py_eval_pos_cb, evaluator, ids=None):
+    ids = _ids_of(reqs) if ids is None else ids
     if (py_eval_pos_cb is None) == (evaluator is None):
         raise TypeError("pass exactly one of py_eval_pos_cb (numpy callback) or evaluator= (device callable)")
     if int(max_nn_batch_size) < 1 or int(n_mcts_iterations) < 0:
         raise ValueError("max_nn_batch_size must be >= 1 and n_mcts_iterations >= 0")
     multi = evaluator is not None and isinstance(evaluator, dict)
-    if evaluator is not None and not multi and any(r.player0_id != r.player1_id for r in reqs):
+    if evaluator is not None and not multi and bool((ids[:, 1] != ids[:, 2]).any()):
         raise TypeError("games between different models need evaluator={model_id: evaluator, ...}")
     if multi:
-        missing = {m for r in reqs for m in (r.player0_id, r.player1_id)} - set(evaluator)
+        missing = set(np.unique(ids[:, 1:]).tolist()) - set(evaluator)
         if missing:
             raise KeyError(f"no evaluator for model ids {sorted(missing)}")
     return multi
@@ -197,13 +222,14 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
     reqs = list(reqs)
     if py_eval_pos_cb is not None and evaluator is None and getattr(py_eval_pos_cb, "device_evaluator", None) is not None:
         evaluator, py_eval_pos_cb = py_eval_pos_cb.device_evaluator, None
-    _validate(reqs, max_nn_batch_size, n_mcts_iterations, py_eval_pos_cb, evaluator)
+    metas = _ids_of(reqs)               # u64 ids, as extract() checks (pybridge.rs:30)
+    _validate(reqs, max_nn_batch_size, n_mcts_iterations, py_eval_pos_cb, evaluator, metas)
     if not reqs:
         return PlayGamesResult([])
-    metas = [GameMetadata(r.game_id, r.player0_id, r.player1_id) for r in reqs]
-    recs, counts = _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator,
-                         device, resident_games, planes_dtype, blocks_per_slot, stats, dirichlet, concurrent_sessions,
-                         eval_cache_entries, on_device=False, reclaim=reclaim, reclaim_period=reclaim_period)
+    recs, counts = _play(metas, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator,
+                         device=device, resident_games=resident_games, planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot, stats=stats,
+                         dirichlet=dirichlet, concurrent_sessions=concurrent_sessions, eval_cache_entries=eval_cache_entries, on_device=False,
+                         reclaim=reclaim, reclaim_period=reclaim_period)
     return results_from_records(metas, recs, counts)
 
 
@@ -242,19 +268,21 @@ def merge_parts(n_games: int, parts):
     return out, counts
 
 
-def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator, device,
-          resident_games, planes_dtype, blocks_per_slot, stats, dirichlet, concurrent_sessions, eval_cache_entries, on_device,
-          reclaim=None, reclaim_period=0):
-    """Play `reqs` on ONE device.  Returns (records, counts) in request order; `records` is a numpy
+def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator, device=None,
+          resident_games=None, planes_dtype=None, blocks_per_slot=0, stats=None, dirichlet=None, concurrent_sessions=None,
+          eval_cache_entries=0, on_device=False, reclaim=None, reclaim_period=0):
+    """Play `reqs` (a uint64[n, 3] table of ids, or GameMetadata-like objects) on ONE device.  Returns (records, counts) in request order; `records` is a numpy
     SAMPLE_DTYPE array, or with on_device=True a uint8[n, 64] tensor that never left the GPU (packed
     by k_pack_samples: what the sample all-gather of the multi-GPU path sends)."""
     from .session import run_sessions
 
+    if not isinstance(reqs, np.ndarray):
+        reqs = _ids_of(reqs)
     multi = evaluator is not None and isinstance(evaluator, dict)
-    n_slots = min(len(reqs), int(resident_games) if resident_games else DEFAULT_RESIDENT_GAMES)
     if planes_dtype is None:   # hand a bf16 network bf16 planes (0/1 are exact): no conversion kernel per step
         planes_dtype = torch.bfloat16 if getattr(evaluator, "dtype", None) == torch.bfloat16 else torch.float32
     graph_safe = evaluator is not None and not multi and getattr(evaluator, "graph_safe", False)
+    n_slots = min(len(reqs), int(resident_games) if resident_games else default_resident_games(len(reqs), int(n_mcts_iterations), graph_safe, device))
     # Device evaluators that are pure device code: the resident games are split over sessions that run
     # concurrently on their own streams (session.run_sessions), two by default when each half still
     # fills the GEMMs.  Which session plays a game does not change its samples.
@@ -264,13 +292,24 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
     parts = max(1, min(parts, n_slots))
     if eval_cache_entries and multi:
         raise TypeError("eval_cache_entries needs ONE evaluator (not evaluator={model_id: ...})")
-    # longer graphs amortise the replay boundary (+2.5 % at 32); all but very long jobs keep the finer
-    # stop granularity (a 16 384-game job: 16.0 k games/s at 8 steps per graph, 14.9 k at 32)
-    # ... and jobs of few but long games (the reference's default job: 1 700 games, n = 1 400: 37 000 rounds) replay 32 rounds
-    # per graph too: the stop granularity is then 0.1 % of the job and the replay boundary 1.5 us per round at 8
-    steps_per_graph = (32 if (len(reqs) >= 32 * n_slots or int(n_mcts_iterations) >= 400) else 8) if graph_safe else 0
+    # Rounds per HIP-graph replay.  Long graphs amortise the replay boundary (BASELINE config 2, two sessions: 0.109 ms per round at
+    # 8 rounds per replay, 0.104 at 64) but the job's end is only noticed between replays, and up to three may be in flight.  So: long
+    # graphs while the job is long -- judged by the rounds it will take, ~15 moves x n simulations per generation of games -- and,
+    # for two paired sessions, short ones from the first narrowing of the tail on, where the graph is captured again anyway
+    # (session._run_pair).  The reference's default job (1 700 games, n = 1 400: 37 000 rounds, one session) replays 32.
+    est_rounds = -(-len(reqs) // max(1, n_slots)) * 15 * max(1, int(n_mcts_iterations))
+    if not graph_safe:
+        steps_per_graph = tail_steps_per_graph = 0
+    elif parts == 2:
+        steps_per_graph = 64 if est_rounds >= 4000 else (32 if est_rounds >= 1500 else 8)
+        tail_steps_per_graph = 16 if steps_per_graph >= 32 else 8
+    else:
+        steps_per_graph = tail_steps_per_graph = 32 if (len(reqs) >= 32 * n_slots or int(n_mcts_iterations) >= 400) else 8
     if hasattr(evaluator, "latency_mode"):   # InferenceNet: tile choice of the narrow layers, alone vs beside another session
         evaluator.latency_mode = parts == 1
+    import time
+    phases = {} if stats is not None else None
+    t_play0 = time.perf_counter()
     sessions = []
     try:
         for p in range(parts):   # session p plays requests p, p + parts, ...
@@ -279,32 +318,45 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
             s = DeviceSession(max(1, slots), n_mcts_iterations, c_exploration, c_ply_penalty, device=device,
                               planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot, reclaim=reclaim, reclaim_period=reclaim_period)
             sessions.append(s)
-            s.set_games([(r.game_id, r.player0_id, r.player1_id) for r in mine])
+            s.set_games(mine)
             if dirichlet is not None:   # extension: (alpha, epsilon) root noise; the reference has none
                 s.set_dirichlet(*dirichlet)
             if eval_cache_entries:      # extension: evaluation cache, each session keeps its own table
                 s.set_eval_cache(max(1024, int(eval_cache_entries) // parts))
+        t_run0 = time.perf_counter()
         if parts > 1:
-            steps = max(run_sessions(sessions, evaluator, steps_per_graph=steps_per_graph))
+            steps = max(run_sessions(sessions, evaluator, steps_per_graph=steps_per_graph, phases=phases, tail_steps_per_graph=tail_steps_per_graph))
         elif evaluator is None:
-            p0 = np.array([r.player0_id for r in reqs], dtype=np.uint64)
-            p1 = np.array([r.player1_id for r in reqs], dtype=np.uint64)
-            ev = _CallbackEvaluator(sessions[0], py_eval_pos_cb, max_nn_batch_size, p0, p1)
+            ev = _CallbackEvaluator(sessions[0], py_eval_pos_cb, max_nn_batch_size, reqs[:, 1], reqs[:, 2])
             steps = sessions[0].run(ev, poll_every=4)   # the completion probe every 4th step: at most 3 idle steps at the very end
         elif multi:
             steps = sessions[0].run(_MultiModelEvaluator(sessions[0], evaluator))
         else:
             # a c4a0_amd.nn.InferenceNet is pure device code: replay it and the step kernel from a HIP graph
             steps = sessions[0].run(evaluator, steps_per_graph=steps_per_graph)
+        t_drain0 = time.perf_counter()
         pieces = []
+        merge_on_device = on_device or parts > 1   # several sessions: interleave their records on the device, ONE transfer to the host
         for p, s in enumerate(sessions):
             pos = np.arange(p, len(reqs), parts, dtype=np.int64)
-            pieces.append((pos, s.sample_counts(), s.pack_samples_device() if on_device else s.drain_samples()))
+            pieces.append((pos, s.sample_counts(), s.pack_samples_device() if merge_on_device else s.drain_samples()))
         if parts == 1:
             recs, counts = pieces[0][2], pieces[0][1]
         else:
             recs, counts = merge_parts(len(reqs), pieces)
+        if merge_on_device and not on_device:
+            from .session import SAMPLE_DTYPE
+            recs = recs.cpu().numpy().reshape(-1).view(SAMPLE_DTYPE)
         if stats is not None:
+            t_end = time.perf_counter()
+            # where the call's wall time went (seconds): session set-up, graph captures, the rounds until every request had been
+            # started ("steady": all slots busy), the rounds after that ("tail": finished slots stay empty), the sample hand-over
+            t_loop0 = phases.get("t_loop0", t_run0)
+            t_started = phases.get("t_all_started", t_drain0)
+            stats["phases"] = {"setup_s": t_run0 - t_play0, "start_and_capture_s": t_loop0 - t_run0, "steady_s": t_started - t_loop0,
+                               "tail_s": t_drain0 - t_started, "drain_s": t_end - t_drain0, "graph_captures": phases.get("captures", 0),
+                               "recapture_s_inside_steady_and_tail": phases.get("recapture_s", 0.0),
+                               "rounds_until_all_started": phases.get("steps_all_started"), "narrowings": phases.get("narrowings", [])}
             tot = {}
             for s in sessions:
                 for k, v in s.counters().items():

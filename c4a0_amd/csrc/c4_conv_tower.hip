@@ -811,6 +811,8 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   // 2 = 8 boards / 8 wavefronts, 3 = 16 boards / 12 wavefronts (27.3 vs 28.0 us alone at 2 048 boards, no difference
   // in the bench).  64 channels: 2 / 3 / 4 below (1 = the default).
   if (config > 4 || (channels == 32 && config == 4)) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config must be 0 (automatic) .. 3 (32 channels) / .. 4 (64 channels)");
+  if (channels == 64 && config == 4 && Geo<64, 8>::kLdsBytes + 64 + 4 * RingFeed<64>::kStageSlots * 16 + 2 * (int)n_blocks * 64 * 4 > 160 * 1024)
+    return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config 4 (weights through an LDS ring) keeps the layers' biases in LDS behind the ring: at most 23 residual blocks");   // an explicitly asked-for shape is run or refused, never swapped for another
   if (channels == 32 && config == 1) return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32 && config == 2) return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32 && config == 3) return launch_tower<32, 16, 768, 1>(p, n_boards, (hipStream_t)stream, device);

@@ -1097,19 +1097,19 @@ __global__ __launch_bounds__(256) void k_compact_move(Params p, const CompactPla
 // ------------------------------------------------------------------------------------------
 constexpr int kReclaimThreads = 1024;
 constexpr uint32_t kReclaimSlotsPerGroup = 16;            // slots one workgroup looks at (a look is one 8-byte load; few slots ever need more)
-C4_DEV void reclaim_slot(const Params& p, uint32_t g, uint32_t min_free, uint32_t& s_tail);
+C4_DEV void reclaim_slot(const Params& p, uint32_t g, uint32_t min_free, uint32_t& s_tail, uint32_t& s_overflow);
 __global__ __launch_bounds__(kReclaimThreads) void k_arena_reclaim(Params p, uint32_t min_free) {
-  __shared__ uint32_t s_tail;
+  __shared__ uint32_t s_tail, s_overflow;
   // one workgroup per 16 slots, one after the other (the test is workgroup-uniform): a launch that finds nothing to do is ~100
   // workgroups that return after 16 loads, not one 1 024-thread workgroup per slot
   for (uint32_t k = 0; k < kReclaimSlotsPerGroup; k++) {
     const uint32_t g = blockIdx.x * kReclaimSlotsPerGroup + k;
     if (g >= p.n_slots) return;
-    reclaim_slot(p, g, min_free, s_tail);
+    reclaim_slot(p, g, min_free, s_tail, s_overflow);
     __syncthreads();
   }
 }
-C4_DEV void reclaim_slot(const Params& p, const uint32_t g, const uint32_t min_free, uint32_t& s_tail) {
+C4_DEV void reclaim_slot(const Params& p, const uint32_t g, const uint32_t min_free, uint32_t& s_tail, uint32_t& s_overflow) {
   Slot* st = p.slots + g;
   const uint32_t state = st->state, arena = st->arena;
   if (slot_status(state) != kActive) return;
@@ -1127,7 +1127,7 @@ C4_DEV void reclaim_slot(const Params& p, const uint32_t g, const uint32_t min_f
     reinterpret_cast<uint4*>(blocks + dst + 1)[sub] = load_block_lane(blocks, root_block, sub);
     if (sub == 7) blocks[root_block].t.legal = (uint16_t)(dst + 1);
   }
-  if (tid == 0) s_tail = dst + (root_block ? 2u : 1u);
+  if (tid == 0) { s_tail = dst + (root_block ? 2u : 1u); s_overflow = 0u; }
   __syncthreads();
   uint32_t lo = dst + 1, hi = s_tail;
   while (lo < hi) {                                       // one level of the tree per trip
@@ -1144,6 +1144,14 @@ C4_DEV void reclaim_slot(const Params& p, const uint32_t g, const uint32_t min_f
       if (cnt == 0) continue;                             // (group-uniform)
       uint32_t base = sub == 0 ? atomicAdd(&s_tail, cnt) : 0u;
       base = shfl_u32(base, gbase);
+      // The host sizes the halves so that the live subtree always fits (reclaim_half_min); should that ever not hold (a damaged
+      // tree, a configuration changed under a running game), nothing is written past the destination half -- an upward copy
+      // would run into the NEXT slot's arena, a downward one into the half still being read -- and the slot raises the error the
+      // step kernel raises for a full arena, with its root, links and path left as they were.
+      if (base + cnt > dst + H) {                         // (group-uniform)
+        if (sub == 0) s_overflow = 1u;
+        continue;
+      }
       uint4 v[7];
 #pragma unroll
       for (int k = 0; k < 7; k++) if (link[k]) v[k] = load_block_lane(blocks, link[k], sub);
@@ -1165,7 +1173,12 @@ C4_DEV void reclaim_slot(const Params& p, const uint32_t g, const uint32_t min_f
     }
     __syncthreads();                                      // this level's copies (and forwarding addresses) are visible to the workgroup
     lo = hi; hi = s_tail;
+    if (s_overflow) hi = lo;                              // (workgroup-uniform: read between two barriers) stop walking
     __syncthreads();
+  }
+  if (s_overflow) {
+    if (tid == 0) raise_error(p, st, g, C4_ERR_ARENA_OVERFLOW);
+    return;
   }
   // the recorded path: level L sits at path[4 (L & 3) + (L >> 2)] (L < 16) or path_deep[L - 16]; level 0 is the root's own entry
   if (tid <= depth && tid < kMaxPath) {
@@ -1598,7 +1611,7 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
   // job (C4_ERR_ARENA_OVERFLOW loses the whole call), so the default sizing is refused here, with the
   // reason; a caller who knows its games are short may still pass blocks_per_slot explicitly.
   // (From round 5 the default sizing switches to a RECLAIMED arena above 1 000 iterations, see C4_FLAG_RECLAIM: the live subtree is at
-  // most n + a few blocks, so two halves of 3 n + 280 blocks serve any game and the links stay 16 bits wide up to n = 32 400.)
+  // most n + a few blocks, so two halves of 2.5 n + 554 blocks (reclaim_half_min + 1.5 n of slack) serve any game and the links stay 16 bits wide up to n = 32 213.)
   if (reclaim_mode(cfg)) {
     const uint32_t period = cfg->reclaim_period ? cfg->reclaim_period : kReclaimPeriod;
     const uint64_t need = reclaim_half_min(cfg->n_mcts_iterations, period, 2);
@@ -1607,7 +1620,7 @@ int c4_session_create(const c4_config* cfg, c4_session** out) {
     if (cfg->flags & C4_FLAG_NO_RECLAIM) return fail(C4_ERR_BAD_ARG, "C4_FLAG_RECLAIM and C4_FLAG_NO_RECLAIM exclude each other");
     if (period > 4096) return fail(C4_ERR_BAD_ARG, "reclaim_period is limited to 4096 step launches");
     if (half < need)
-      return fail(C4_ERR_BAD_ARG, "reclaimed arena too small: each half must hold the live subtree (n_mcts_iterations + 16 blocks) and the blocks of 4 x "
+      return fail(C4_ERR_BAD_ARG, "reclaimed arena too small: each half must hold the live subtree (n_mcts_iterations + simulations per launch + 8 blocks) and the blocks of 4 x "
                                   "reclaim_period step launches (" + std::to_string(need) + " blocks per half, i.e. blocks_per_slot >= " + std::to_string(2 * need) +
                                   "; a half is at most 32 767 blocks: n_mcts_iterations <= " + std::to_string(kMaxBlocksPerSlot / 2 - (need - cfg->n_mcts_iterations)) + ")");
   } else if (cfg->blocks_per_slot == 0 && 43ull * cfg->n_mcts_iterations + 8 > kMaxBlocksPerSlot)
@@ -1777,6 +1790,10 @@ int c4_session_set_eval_cache(c4_session* s, uint64_t n_entries, uint32_t max_si
   if (s->p.half_blocks) {   // a reclaimed half holds the blocks of 4 x reclaim_period launches: as many simulations per launch as that allows
     if (s->p.max_sims > kReclaimMaxSims) s->p.max_sims = kReclaimMaxSims;
     while (s->p.max_sims > 2 && reclaim_half_min(s->p.n_iter, s->reclaim_period, s->p.max_sims) > s->p.half_blocks) s->p.max_sims--;
+    // more simulations per launch = a larger margin to keep free: the next step launch is followed by a look at the arenas with
+    // the new margin, whatever the count since the last one (a slot left with just over the OLD margin could otherwise
+    // take reclaim_period launches of the new width before the next look)
+    s->reclaim_count = 0;
   }
   return C4_OK;
 }

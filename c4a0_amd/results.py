@@ -4,7 +4,12 @@ Mirrors (names, arguments, behaviour) the classes the reference registers in
 rust/src/lib.rs:32-35: `GameMetadata` (types.rs:37-60), `Sample` (types.rs:103-153),
 `GameResult` (types.rs:63-100) and `PlayGamesResult` (pybridge.rs:58-158), so that the
 reference's callers (src/c4a0/training.py:179-207,317-333; tournament.py:84-139) work on
-GPU-generated games unchanged.  Host-side bookkeeping only; nothing here is on the hot path.
+GPU-generated games unchanged.  Host-side bookkeeping: a result stays the packed 64-byte records
+the GPU handed over (and a games x 3 table of ids) for as long as nobody asks for Python objects;
+the wire format (`to_cbor` / `from_cbor` / pickling) and the train / test permutation run in the
+library's host functions (include/c4a0_hip.h c4_records_to_cbor, c4_cbor_to_records,
+c4_shuffle_games) on those arrays.  The pure-Python codec further down (`_py_to_cbor`,
+`_py_from_cbor`) is what the tests check the native one against; the product does not call it.
 """
 from __future__ import annotations
 
@@ -77,12 +82,16 @@ class Sample:
         self.q_no_penalty = np.float32(q_no_penalty)
 
     @classmethod
-    def _from_row(cls, recs: np.ndarray, pol: np.ndarray, i: int) -> "Sample":
-        s = cls.__new__(cls)
-        s.mask, s.value = int(recs["mask"][i]), int(recs["value"][i])
-        s.policy = pol[i].copy()
-        s.q_penalty, s.q_no_penalty = recs["q_penalty"][i], recs["q_no_penalty"][i]
-        return s
+    def _bulk(cls, recs: np.ndarray) -> List["Sample"]:
+        """One Sample per record, built from whole-column conversions (no per-sample numpy field access)."""
+        new = cls.__new__
+        pol = np.ascontiguousarray(recs["policy"])          # one copy; each sample's policy is its row (a view of this block)
+        out = []
+        for m, v, p, a, b in zip(recs["mask"].tolist(), recs["value"].tolist(), pol, list(recs["q_penalty"]), list(recs["q_no_penalty"])):
+            s = new(cls)
+            s.mask, s.value, s.policy, s.q_penalty, s.q_no_penalty = m, v, p, a, b
+            out.append(s)
+        return out
 
     def flip_h(self) -> "Sample":  # types.rs:115-122
         return Sample(flip_h_bits(self.mask), flip_h_bits(self.value), self.policy[::-1].copy(), self.q_penalty, self.q_no_penalty)
@@ -232,33 +241,110 @@ class _CborReader:
             yield want
 
 
+def _py_to_cbor(results: Sequence[GameResult]) -> bytes:
+    """The wire format written sample by sample in Python: the CHECKER of the library's encoder (tests), not a product path."""
+    out = [_cbor_uint(5, 1), _K["results"], _cbor_uint(4, len(results))]
+    for r in results:
+        m = r.metadata
+        out += [_cbor_uint(5, 2), _K["metadata"], _cbor_uint(5, 3),
+                _K["game_id"], _cbor_uint(0, m.game_id), _K["player0_id"], _cbor_uint(0, m.player0_id),
+                _K["player1_id"], _cbor_uint(0, m.player1_id),
+                _K["samples"], _cbor_uint(4, len(r.samples))]
+        for s in r.samples:
+            out += [_cbor_uint(5, 4), _K["pos"], _cbor_uint(5, 2), _K["mask"], _cbor_uint(0, s.mask),
+                    _K["value"], _cbor_uint(0, s.value), _K["policy"], _cbor_uint(4, 7)]
+            out += [_cbor_f32(p) for p in s.policy]
+            out += [_K["q_penalty"], _cbor_f32(s.q_penalty), _K["q_no_penalty"], _cbor_f32(s.q_no_penalty)]
+    return b"".join(out)
+
+
+def _py_from_cbor(cbor: bytes) -> List[GameResult]:
+    """The checker of the library's decoder (tests), not a product path."""
+    try:
+        r = _CborReader(cbor)
+        results = []
+        for _ in r.struct_fields(["results"]):
+            for _g in range(r.length(4)):
+                meta, samples = None, []
+                for f in r.struct_fields(["metadata", "samples"]):
+                    if f == "metadata":
+                        vals = [r.uint() for _ in r.struct_fields(["game_id", "player0_id", "player1_id"])]
+                        meta = GameMetadata(*vals)
+                    else:
+                        for _s in range(r.length(4)):
+                            d = {}
+                            for sf in r.struct_fields(["pos", "policy", "q_penalty", "q_no_penalty"]):
+                                if sf == "pos":
+                                    d["pos"] = [r.uint() for _ in r.struct_fields(["mask", "value"])]
+                                elif sf == "policy":
+                                    if r.length(4) != 7:
+                                        raise ValueError("policy must have 7 entries")
+                                    d["policy"] = [r.f32() for _ in range(7)]
+                                else:
+                                    d[sf] = r.f32()
+                            samples.append(Sample(d["pos"][0], d["pos"][1], d["policy"], d["q_penalty"], d["q_no_penalty"]))
+                results.append(GameResult(meta, samples))
+        if r.i != len(cbor):
+            raise ValueError("trailing bytes")
+        return results
+    except (IndexError, struct.error) as e:  # truncated input
+        raise ValueError(f"invalid CBOR: {e}") from e
+
+
+def _native():
+    """(library, check): the host-side record functions of libc4a0_hip.so.  Missing library = ImportError with the build
+    command (c4a0_amd._lib): there is no Python path behind it."""
+    from . import _lib
+
+    return _lib.lib(), _lib.check
+
+
+def _sample_dtype():
+    from .session import SAMPLE_DTYPE
+
+    return SAMPLE_DTYPE
+
+
+def _ids_table(reqs) -> np.ndarray:
+    """uint64[n, 3] (game_id, player0_id, player1_id) from GameMetadata-like objects or an array of that shape."""
+    if isinstance(reqs, np.ndarray):
+        return np.ascontiguousarray(reqs, dtype=np.uint64).reshape(-1, 3)
+    return np.array([(r.game_id, r.player0_id, r.player1_id) for r in reqs], dtype=np.uint64).reshape(-1, 3)
+
+
 class PlayGamesResult:
     """pybridge.rs:58-158.  `score_policies` needs the external PascalPons solver and the
     rocksdb cache (rust/src/solver.rs) -- out of scope, raises NotImplementedError."""
 
     def __init__(self, results: Iterable[GameResult] = ()):  # pybridge.rs:67-70: empty constructor for unpickling
         self._results: List[GameResult] = list(results)
-        self._lazy = None   # (reqs, records, counts) straight from the GPU; objects are built on first access
+        self._lazy = None   # (ids uint64[n,3], records, counts uint32[n]): the arrays as handed over; objects are built on first access
 
     @classmethod
-    def _from_records(cls, reqs: Sequence[GameMetadata], recs: np.ndarray, counts: np.ndarray) -> "PlayGamesResult":
+    def _from_records(cls, reqs, recs: np.ndarray, counts: np.ndarray) -> "PlayGamesResult":
         out = cls()
-        out._lazy = (list(reqs), recs, np.asarray(counts))
+        ids = _ids_table(reqs)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        if len(ids) != len(counts) or int(counts.sum(dtype=np.int64)) != len(recs):
+            raise ValueError("records, counts and requests do not describe the same games")
+        out._lazy = (ids, recs, counts)
         return out
 
     @property
     def results(self) -> List[GameResult]:
-        """`Vec<GameResult>` (pybridge.rs:61-62).  A GPU run hands over ~300 k samples per second of
+        """`Vec<GameResult>` (pybridge.rs:61-62).  A GPU run hands over ~500 k samples per second of
         play; the per-sample Python objects are only built when somebody asks for them."""
         if self._lazy is not None:
-            reqs, recs, counts = self._lazy
+            ids, recs, counts = self._lazy
             self._lazy = None
+            samples = Sample._bulk(recs)
             out, off = [], 0
-            pol = recs["policy"]
-            for meta, n in zip(reqs, counts.tolist()):
-                samples = [Sample._from_row(recs, pol, i) for i in range(off, off + n)]
+            new = GameMetadata.__new__
+            for (gid, p0, p1), n in zip(ids.tolist(), counts.tolist()):
+                m = new(GameMetadata)
+                m.game_id, m.player0_id, m.player1_id = gid, p0, p1
+                out.append(GameResult(m, samples[off:off + n]))
                 off += n
-                out.append(GameResult(meta, samples))
             self._results = out
         return self._results
 
@@ -267,129 +353,136 @@ class PlayGamesResult:
         self._lazy = None
         self._results = list(value)
 
+    def __len__(self) -> int:
+        """Number of games (extension; does not build objects)."""
+        return len(self._lazy[0]) if self._lazy is not None else len(self._results)
+
+    def _tables(self):
+        """(ids uint64[n,3], records, counts uint32[n]) of this result, whichever form it is held in."""
+        if self._lazy is not None:
+            return self._lazy
+        counts = np.array([len(r.samples) for r in self._results], dtype=np.uint32)
+        recs = np.zeros(int(counts.sum(dtype=np.int64)), dtype=_sample_dtype())
+        ss = [s for r in self._results for s in r.samples]
+        if ss:
+            recs["game_id"] = np.repeat(np.array([r.metadata.game_id for r in self._results], dtype=np.uint64), counts.astype(np.int64))
+            recs["mask"] = np.array([s.mask for s in ss], dtype=np.uint64)
+            recs["value"] = np.array([s.value for s in ss], dtype=np.uint64)
+            recs["policy"] = np.array([s.policy for s in ss], dtype=np.float32).reshape(-1, 7)
+            recs["q_penalty"] = np.array([s.q_penalty for s in ss], dtype=np.float32)
+            recs["q_no_penalty"] = np.array([s.q_no_penalty for s in ss], dtype=np.float32)
+            ends = np.cumsum(counts.astype(np.int64))
+            idx = np.arange(len(recs), dtype=np.int64) - np.repeat(ends - counts, counts.astype(np.int64))
+            recs["meta"] = idx.astype(np.uint32)
+            recs["meta"][ends[counts > 0] - 1] |= np.uint32(1 << 16)
+        return _ids_table([r.metadata for r in self._results]), recs, counts
+
     def to_records(self):
         """(records, counts): the packed 64-byte sample records (c4a0_amd.session.SAMPLE_DTYPE) in result
         order and the number of samples of every game -- the form the GPU hands over (extension)."""
-        if self._lazy is not None:
-            _reqs, recs, counts = self._lazy
-            return recs, np.asarray(counts).astype(np.uint32)
-        from .session import SAMPLE_DTYPE
-
-        counts = np.array([len(r.samples) for r in self._results], dtype=np.uint32)
-        recs = np.zeros(int(counts.sum()), dtype=SAMPLE_DTYPE)
-        k = 0
-        for r in self._results:
-            for i, s in enumerate(r.samples):
-                recs[k] = (r.metadata.game_id, s.mask, s.value, np.asarray(s.policy, dtype=np.float32), s.q_penalty, s.q_no_penalty,
-                           i | ((1 << 16) if i == len(r.samples) - 1 else 0))
-                k += 1
+        _ids, recs, counts = self._tables()
         return recs, counts
 
     def to_arrays(self):
         """Bulk view for training code (extension; the reference only has per-sample `to_numpy`):
         (planes float32[N,2,6,7], policy float32[N,7], q_penalty float32[N], q_no_penalty float32[N],
         game_index int64[N]) over all samples in result order, without building Python objects."""
-        if self._lazy is not None:
-            _reqs, recs, counts = self._lazy
-            mask, value = recs["mask"], recs["value"]
-            pol, qp, qn = recs["policy"].copy(), recs["q_penalty"].copy(), recs["q_no_penalty"].copy()
-            gidx = np.repeat(np.arange(len(counts), dtype=np.int64), counts.astype(np.int64))
-        else:
-            ss = [(gi, s) for gi, r in enumerate(self._results) for s in r.samples]
-            mask = np.array([s.mask for _, s in ss], dtype=np.uint64)
-            value = np.array([s.value for _, s in ss], dtype=np.uint64)
-            pol = np.array([s.policy for _, s in ss], dtype=np.float32).reshape(-1, 7)
-            qp = np.array([s.q_penalty for _, s in ss], dtype=np.float32)
-            qn = np.array([s.q_no_penalty for _, s in ss], dtype=np.float32)
-            gidx = np.array([gi for gi, _ in ss], dtype=np.int64)
+        _ids, recs, counts = self._tables()
+        mask, value = recs["mask"], recs["value"]
+        pol, qp, qn = recs["policy"].copy(), recs["q_penalty"].copy(), recs["q_no_penalty"].copy()
+        gidx = np.repeat(np.arange(len(counts), dtype=np.int64), counts.astype(np.int64))
         bits = np.arange(42, dtype=np.uint64)[None, :]
         p0 = ((value[:, None] >> bits) & np.uint64(1)).astype(np.float32)
         p1 = (((mask & ~value)[:, None] >> bits) & np.uint64(1)).astype(np.float32)
         planes = np.concatenate([p0, p1], axis=1).reshape(-1, 2, N_ROWS, N_COLS)
         return planes, pol, qp, qn, gidx
 
-    # -- serialisation (pybridge.rs:73-92)
+    # -- serialisation (pybridge.rs:73-92): the library's host codec on the packed records (c4_records_to_cbor / c4_cbor_to_records)
     def to_cbor(self) -> bytes:
-        out = [_cbor_uint(5, 1), _K["results"], _cbor_uint(4, len(self.results))]
-        for r in self.results:
-            m = r.metadata
-            out += [_cbor_uint(5, 2), _K["metadata"], _cbor_uint(5, 3),
-                    _K["game_id"], _cbor_uint(0, m.game_id), _K["player0_id"], _cbor_uint(0, m.player0_id),
-                    _K["player1_id"], _cbor_uint(0, m.player1_id),
-                    _K["samples"], _cbor_uint(4, len(r.samples))]
-            for s in r.samples:
-                out += [_cbor_uint(5, 4), _K["pos"], _cbor_uint(5, 2), _K["mask"], _cbor_uint(0, s.mask),
-                        _K["value"], _cbor_uint(0, s.value), _K["policy"], _cbor_uint(4, 7)]
-                out += [_cbor_f32(p) for p in s.policy]
-                out += [_K["q_penalty"], _cbor_f32(s.q_penalty), _K["q_no_penalty"], _cbor_f32(s.q_no_penalty)]
-        return b"".join(out)
+        import ctypes as C
+
+        L, check = _native()
+        ids, recs, counts = self._tables()
+        recs = np.ascontiguousarray(recs)
+        n = C.c_uint64()
+        args = (ids.ctypes.data, counts.ctypes.data, len(counts), recs.ctypes.data, len(recs))
+        check(L.c4_records_to_cbor(*args, None, 0, C.byref(n)))          # the document's size
+        # the bytes object the caller gets, written in place (a bytes object may be filled by its creator before anyone else
+        # sees it -- CPython's documented use of PyBytes_FromStringAndSize(NULL, n)): no staging buffer, no copy of 100 bytes per sample
+        new_bytes = C.pythonapi.PyBytes_FromStringAndSize
+        new_bytes.restype, new_bytes.argtypes = C.py_object, [C.c_char_p, C.c_ssize_t]
+        as_ptr = C.pythonapi.PyBytes_AsString
+        as_ptr.restype, as_ptr.argtypes = C.c_void_p, [C.py_object]
+        out = new_bytes(None, n.value)
+        check(L.c4_records_to_cbor(*args, as_ptr(out), n.value, C.byref(n)))
+        return out
 
     @staticmethod
     def from_cbor(cbor: bytes) -> "PlayGamesResult":
+        """pybridge.rs:80-92.  The result stays in record form (no per-sample objects) until `.results` is read."""
+        import ctypes as C
+
+        from ._lib import C4Error
+        L, check = _native()
+        src = np.frombuffer(cbor, dtype=np.uint8)          # no copy; bytes, bytearray, memoryview
+        # one pass: a game takes at least 53 bytes of the document and a sample at least 59, which bounds the tables
+        # (untouched pages of the over-sized arrays are never made resident)
+        cap_games, cap_recs = len(src) // 53 + 1, len(src) // 59 + 1
+        ids = np.empty((cap_games, 3), dtype=np.uint64)
+        counts = np.empty(cap_games, dtype=np.uint32)
+        recs = np.empty(cap_recs, dtype=_sample_dtype())
+        n_games, n_recs = C.c_uint64(), C.c_uint64()
         try:
-            r = _CborReader(cbor)
-            results = []
-            for _ in r.struct_fields(["results"]):
-                for _g in range(r.length(4)):
-                    meta, samples = None, []
-                    for f in r.struct_fields(["metadata", "samples"]):
-                        if f == "metadata":
-                            vals = [r.uint() for _ in r.struct_fields(["game_id", "player0_id", "player1_id"])]
-                            meta = GameMetadata(*vals)
-                        else:
-                            for _s in range(r.length(4)):
-                                d = {}
-                                for sf in r.struct_fields(["pos", "policy", "q_penalty", "q_no_penalty"]):
-                                    if sf == "pos":
-                                        d["pos"] = [r.uint() for _ in r.struct_fields(["mask", "value"])]
-                                    elif sf == "policy":
-                                        if r.length(4) != 7:
-                                            raise ValueError("policy must have 7 entries")
-                                        d["policy"] = [r.f32() for _ in range(7)]
-                                    else:
-                                        d[sf] = r.f32()
-                                samples.append(Sample(d["pos"][0], d["pos"][1], d["policy"], d["q_penalty"], d["q_no_penalty"]))
-                    results.append(GameResult(meta, samples))
-            if r.i != len(cbor):
-                raise ValueError("trailing bytes")
-            return PlayGamesResult(results)
-        except (IndexError, struct.error) as e:  # truncated input
-            raise ValueError(f"invalid CBOR: {e}") from e
+            check(L.c4_cbor_to_records(src.ctypes.data, len(src), ids.ctypes.data, counts.ctypes.data, cap_games,
+                                       recs.ctypes.data, cap_recs, C.byref(n_games), C.byref(n_recs)))
+        except C4Error as e:                               # the reference: ValueError via pyify_err (pybridge.rs:254-259)
+            raise ValueError(str(e)) from None
+        return PlayGamesResult._from_records(ids[: n_games.value], recs[: n_recs.value], counts[: n_games.value])
 
     def __getstate__(self) -> bytes:
         return self.to_cbor()
 
     def __setstate__(self, state: bytes) -> None:
-        self._lazy = None
-        self._results = PlayGamesResult.from_cbor(state).results
+        self._results = []
+        self._lazy = PlayGamesResult.from_cbor(state)._lazy
 
     # -- pybridge.rs:95-106
     def __add__(self, other: "PlayGamesResult") -> "PlayGamesResult":
         if not isinstance(other, PlayGamesResult):
             raise TypeError("can only add PlayGamesResult")
+        if self._lazy is not None and other._lazy is not None:      # stays in record form
+            return PlayGamesResult._from_records(*(np.concatenate([a, b]) for a, b in zip(self._lazy, other._lazy)))
         return PlayGamesResult(self.results + other.results)
 
-    # -- pybridge.rs:110-120.  Whole games go to one side; the permutation is a seeded,
-    # deterministic shuffle (the reference's exact permutation depends on rand 0.10 internals,
-    # which no reference test pins: pybridge_test.py:22-39 only requires determinism and that
-    # `self` is not mutated).
+    # -- pybridge.rs:110-120: `results.shuffle(&mut StdRng::seed_from_u64(seed))`, whole games to one side.  The permutation
+    # is rand's (c4_shuffle_games: seed_from_u64 -> ChaCha12 -> SliceRandom::shuffle), so the reference's training.py:207
+    # gets the partition it would get from c4a0_rust.
     def split_train_test(self, train_frac: float, seed: int) -> Tuple[List[Sample], List[Sample]]:
-        results = list(self.results)
-        np.random.Generator(np.random.PCG64(int(seed) & ((1 << 64) - 1))).shuffle(results)
+        order = shuffled_game_order(len(self), seed)
         # (len as f32 * train_frac).round(): f32 product, then Rust's f32::round = half AWAY from zero
         # (np.round is half-to-even: 5 games at 0.5 must give 3, not 2)
         # ... and Rust's `as usize` saturates: NaN -> 0, negative -> 0, +inf / too large -> usize::MAX (then the
         # slice bound is clamped to len here, where the reference would panic on an out-of-range split)
-        prod = float(np.float32(len(results)) * np.float32(train_frac))
+        n_games = len(order)
+        with np.errstate(over="ignore", invalid="ignore"):
+            prod = float(np.float32(n_games) * np.float32(train_frac))
         if math.isnan(prod) or prod <= 0.0:
             n_train = 0
         elif math.isinf(prod):
-            n_train = len(results)
+            n_train = n_games
         else:
-            n_train = min(len(results), int(math.floor(prod + 0.5)))
-        train = [s for r in results[:n_train] for s in r.samples]
-        test = [s for r in results[n_train:] for s in r.samples]
-        return train, test
+            n_train = min(n_games, int(math.floor(prod + 0.5)))
+        if self._lazy is None:
+            results = [self._results[i] for i in order.tolist()]
+            return [s for r in results[:n_train] for s in r.samples], [s for r in results[n_train:] for s in r.samples]
+        _ids, recs, counts = self._lazy                   # `self` stays in record form (and is not mutated: pybridge_test.py:22-39)
+        c64 = counts.astype(np.int64)
+        starts = np.cumsum(c64) - c64
+        oc = c64[order]
+        idx = np.repeat(starts[order] - (np.cumsum(oc) - oc), oc) + np.arange(int(oc.sum()), dtype=np.int64)
+        samples = Sample._bulk(recs[idx])
+        cut = int(oc[:n_train].sum())
+        return samples[:cut], samples[cut:]
 
     def score_policies(self, solver_path: str, solver_book_path: str, solution_cache_path: str) -> float:
         raise NotImplementedError("score_policies needs the external c4solver binary and book (reference rust/src/solver.rs); out of scope")
@@ -401,10 +494,29 @@ class PlayGamesResult:
         return len({(s.mask, s.value) for r in self.results for s in r.samples})
 
     def __eq__(self, o):
-        return isinstance(o, PlayGamesResult) and self.results == o.results
+        if not isinstance(o, PlayGamesResult):
+            return False
+        if self._lazy is None and o._lazy is None:
+            return self._results == o._results
+        (ia, ra, ca), (ib, rb, cb) = self._tables(), o._tables()
+        if not (np.array_equal(ia, ib) and np.array_equal(ca, cb) and np.array_equal(ra["mask"], rb["mask"]) and np.array_equal(ra["value"], rb["value"])):
+            return False
+        return all(np.ascontiguousarray(ra[f]).tobytes() == np.ascontiguousarray(rb[f]).tobytes() for f in ("policy", "q_penalty", "q_no_penalty"))   # bit for bit, as Sample.__eq__
 
 
-def results_from_records(reqs: Sequence[GameMetadata], recs: np.ndarray, counts: np.ndarray) -> PlayGamesResult:
+def shuffled_game_order(n_games: int, seed: int) -> np.ndarray:
+    """order[i] = index of the game that `results.shuffle(&mut StdRng::seed_from_u64(seed))` (pybridge.rs:111-112) leaves at
+    position i of a list of n_games (int64[n_games]); computed by the library's host function c4_shuffle_games."""
+    import ctypes as C
+
+    L, check = _native()
+    order = np.empty(max(1, n_games), dtype=np.uint32)
+    check(L.c4_shuffle_games(C.c_uint64(int(seed) & ((1 << 64) - 1)), n_games, order.ctypes.data))
+    return order[:n_games].astype(np.int64)
+
+
+def results_from_records(reqs, recs: np.ndarray, counts: np.ndarray) -> PlayGamesResult:
     """Wrap the packed sample records of `c4_session_drain_samples` (records of finished games in
-    reqs order) and the per-game sample counts; `GameResult`/`Sample` objects are created lazily."""
+    reqs order) and the per-game sample counts; `GameResult`/`Sample` objects are created lazily.
+    `reqs`: GameMetadata-like objects, or a uint64[n, 3] array of (game_id, player0_id, player1_id)."""
     return PlayGamesResult._from_records(reqs, recs, counts)

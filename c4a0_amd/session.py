@@ -76,18 +76,21 @@ class DeviceSession:
             pass
 
     # ---------------------------------------------------------------- setup
-    def set_games(self, reqs: Sequence[Tuple[int, int, int]], start_positions: Optional[Sequence[Tuple[int, int]]] = None):
-        n = len(reqs)
-        arr = (GameMetadataC * max(1, n))()
-        for i, (gid, p0, p1) in enumerate(reqs):
-            arr[i] = GameMetadataC(int(gid), int(p0), int(p1))
+    def set_games(self, reqs, start_positions: Optional[Sequence[Tuple[int, int]]] = None):
+        """reqs: (game_id, player0_id, player1_id) triples, or a uint64[n, 3] array of them (no per-game Python work)."""
+        if isinstance(reqs, np.ndarray):
+            tab = np.ascontiguousarray(reqs, dtype=np.uint64).reshape(-1, 3)
+        else:
+            tab = np.array([(int(g), int(a), int(b)) for g, a, b in reqs], dtype=np.uint64).reshape(-1, 3)
+        n = len(tab)
+        arr = C.cast(tab.ctypes.data, C.POINTER(GameMetadataC)) if n else (GameMetadataC * 1)()
         sm = sv = None
         if start_positions is not None:
             if len(start_positions) != n:
                 raise ValueError("start_positions must match reqs")
             sm = (C.c_uint64 * max(1, n))(*[int(m) for m, _ in start_positions])
             sv = (C.c_uint64 * max(1, n))(*[int(v) for _, v in start_positions])
-        check(self.L.c4_session_set_games(self._h, arr, n, sm, sv))
+        check(self.L.c4_session_set_games(self._h, arr, n, sm, sv))   # copies the list (c4a0_hip.h): `tab` may go
         self.n_games = n
         self.rows = self.n_slots
 
@@ -135,6 +138,8 @@ class DeviceSession:
     def set_step_shape(self, games_per_wavefront: int):
         """Games per stepping wavefront of the fused output + step launch: 8 (default) or 4 (c4_session_set_step_shape).  A
         scheduling knob -- the records do not depend on it: 4 is 0.5 % faster beside a second session's kernels, 8 alone."""
+        if not hasattr(self.L, "c4_session_set_step_shape"):   # only an older A/B library (C4A0_HIP_LIB): its one shape is 8
+            return
         check(self.L.c4_session_set_step_shape(self._h, int(games_per_wavefront)))
 
     def round(self, evaluator: DeviceEvaluator):
@@ -390,7 +395,8 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
     for s in sessions:
         s.set_timing(False)
         s.set_step_shape(PAIRED_STEP_GAMES_PER_WAVEFRONT)   # (profiles/r05_out_step_gpw.txt: +0.5 % beside the other session's kernels)
-    # warm the evaluator up outside the capture, once per stream (library handles, lazy module loads)
+    # warm the evaluator up outside the capture, once per stream (library handles, lazy module loads, the LDS opt-in of a tile
+    # shape first used at this width); evaluating the current leaves once more changes nothing a game sees
     for s, st in zip(sessions, streams):
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(st)
@@ -448,7 +454,8 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
 
 
 def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator, steps_per_graph: int = 8,
-                 max_chunks_in_flight: int = 2, paired: Optional[bool] = None) -> List[int]:
+                 max_chunks_in_flight: int = 2, paired: Optional[bool] = None, phases: Optional[dict] = None,
+                 tail_steps_per_graph: Optional[int] = None) -> List[int]:
     """Play the games of several sessions of one device to completion CONCURRENTLY, each session
     replaying its own HIP graph of (evaluator, step kernel) rounds on its own stream.
 
@@ -475,7 +482,7 @@ def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator
         if not paired:
             graphs.append(s.capture_steps(evaluator, steps_per_graph, stream=st))
     if paired:
-        return _run_pair(sessions, streams, evaluator, steps_per_graph, max_chunks_in_flight, invariant)
+        return _run_pair(sessions, streams, evaluator, steps_per_graph, max_chunks_in_flight, invariant, phases, tail_steps_per_graph)
     steps = [0] * len(sessions)
     chunks = [0] * len(sessions)
     live = [s.n_games > 0 for s in sessions]
@@ -509,36 +516,51 @@ def run_sessions(sessions: Sequence["DeviceSession"], evaluator: DeviceEvaluator
     return steps
 
 
-def _run_pair(sessions, streams, evaluator, steps_per_graph, max_chunks_in_flight, invariant) -> List[int]:
+def _run_pair(sessions, streams, evaluator, steps_per_graph, max_chunks_in_flight, invariant, phases=None, tail_steps_per_graph=None) -> List[int]:
     """run_sessions for two sessions of an InferenceNet: ONE graph that pipelines the two explicitly
     (capture_pair), replayed until both sessions' games are over.  A session that finishes first keeps
-    stepping its idle slots until the other is done (its rows are narrowed away like any tail)."""
+    stepping its idle slots until the other is done (its rows are narrowed away like any tail).
+
+    steps_per_graph rounds per replay while slots are refilled (long graphs amortise the replay boundary: at BASELINE
+    config 2, 8 -> 0.109 ms per round, 64 -> 0.104); from the first narrowing on -- the graph has to be captured again there
+    anyway -- tail_steps_per_graph rounds (default: the same), so that the job's end is noticed within a few short replays."""
+    import time
+
     dev = sessions[0].device
+    t_c = time.perf_counter()
     graph = capture_pair(sessions, streams, evaluator, steps_per_graph)
+    if phases is not None:
+        phases.update(first_capture_s=time.perf_counter() - t_c, recapture_s=0.0, captures=1, t_loop0=time.perf_counter())
+    per_graph = steps_per_graph
+    tail_steps = int(tail_steps_per_graph or steps_per_graph)
     steps = 0
-    chunks = 0
+    since_check = 0
     inflight: List[torch.cuda.Event] = []
     while True:
         with torch.cuda.stream(streams[0]):
             graph.replay()
             ev = torch.cuda.Event()
             ev.record(streams[0])
-        steps += steps_per_graph
+        steps += per_graph
+        since_check += per_graph
         inflight.append(ev)
         if len(inflight) > max_chunks_in_flight:   # bounded host run-ahead, as in DeviceSession.run
             inflight.pop(0).synchronize()
-        done_all = True
+        done_all, started_all = True, True
         for s, st in zip(sessions, streams):
             with torch.cuda.stream(st):
-                done, err = s.poll()
+                done, started, err = s.progress()
             if err:
                 torch.cuda.synchronize(dev)
                 s.raise_if_device_error()
             done_all = done_all and done >= s.n_games
+            started_all = started_all and started >= s.n_games
+        if phases is not None and started_all and "t_all_started" not in phases:
+            phases["t_all_started"], phases["steps_all_started"] = time.perf_counter(), steps   # as the (slightly late) probe sees it
         if done_all:
             break
-        chunks += 1
-        if chunks % max(1, sessions[0].NARROW_CHECK_ROUNDS // steps_per_graph) == 0:
+        if since_check >= sessions[0].NARROW_CHECK_ROUNDS and started_all:
+            since_check = 0
             # Both sessions' kernels are nodes of ONE graph replayed on streams[0], and up to max_chunks_in_flight
             # replays are still running here; compact() waits for its session's OWN stream only (B's is streams[1],
             # on which nothing of the replay is visible).  So: decide first, for both, without touching the slots;
@@ -555,7 +577,13 @@ def _run_pair(sessions, streams, evaluator, steps_per_graph, max_chunks_in_fligh
                     if w:
                         s.compact()
                 if [s.rows for s in sessions] != before:   # the old graph carries the old widths
-                    graph = capture_pair(sessions, streams, evaluator, steps_per_graph)
+                    t_c = time.perf_counter()
+                    per_graph = tail_steps
+                    graph = capture_pair(sessions, streams, evaluator, per_graph)
+                    if phases is not None:
+                        phases["recapture_s"] += time.perf_counter() - t_c
+                        phases["captures"] += 1
+                        phases.setdefault("narrowings", []).append((steps, [s.rows for s in sessions]))
     torch.cuda.synchronize(dev)
     for s in sessions:
         s.set_timing(True)

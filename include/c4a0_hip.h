@@ -24,10 +24,10 @@ extern "C" {
 #endif
 
 /* Version of THIS interface: bumped whenever a signature or a struct layout below changes (version 3 added `config` in the
- * middle of c4_conv_tower_bf16's arguments, version 5 c4_session_step_head_out).  A consumer compiled against this header checks it once at start-up --
+ * middle of c4_conv_tower_bf16's arguments, version 5 c4_session_step_head_out, version 8 the host-side record codecs c4_records_to_cbor / c4_cbor_to_records / c4_shuffle_games).  A consumer compiled against this header checks it once at start-up --
  * `if (c4_abi_version() != C4_ABI_VERSION) refuse` -- because the dynamic linker compares names, not signatures
  * (tests/abi_consumer*.c and c4a0_amd/_lib.py do).  No reference counterpart: the reference's boundary is PyO3. */
-#define C4_ABI_VERSION 7
+#define C4_ABI_VERSION 8
 
 #define C4_N_COLS 7          /* rust/src/c4r.rs:45, lib.rs:28 */
 #define C4_N_ROWS 6          /* rust/src/c4r.rs:44, lib.rs:29 */
@@ -248,6 +248,29 @@ int c4_session_pack_samples(c4_session* s, c4_sample_rec* dst_dev, uint64_t cap,
 int c4_session_debug_phase_stamps(c4_session* s, uint64_t* out_host, uint64_t cap_words, uint64_t* n_words);
 /* Device views for collectives (RCCL all-gather of samples): records [n_games][43], counts [n_games]. */
 int c4_session_sample_store(c4_session* s, const c4_sample_rec** recs_dev, const uint32_t** counts_dev, uint64_t* n_games);
+
+/* ---- the hand-off right after the path: PlayGamesResult's wire format on the packed records (HOST functions: no device is
+ * touched, they work on a machine without a GPU). ----
+ * PlayGamesResult::to_cbor / __getstate__ (rust/src/pybridge.rs:73-92: `serde_cbor::to_vec(self)`; what `pickle.dump(games, f)` of
+ * src/c4a0/training.py:62-63 runs every generation): games g = 0 .. n_games-1 with metadata metas[g] (types.rs:37-48) and counts[g]
+ * samples each, the samples being consecutive entries of recs (pos, policy, q_penalty, q_no_penalty of types.rs:103-110; game_id
+ * and meta of the records are not part of the wire format), written to dst as serde_cbor 0.11.2 writes the derive(Serialize)
+ * structs: definite-length maps keyed by field name in declaration order, shortest-form unsigned integers, f32 as a half float
+ * where that is lossless.  Two-call pattern: dst == NULL -> *n_written = the size of the document; then written to dst (cap >= it). */
+int c4_records_to_cbor(const c4_game_metadata* metas, const uint32_t* counts, uint64_t n_games, const c4_sample_rec* recs,
+                       uint64_t n_records, uint8_t* dst, uint64_t cap, uint64_t* n_written);
+/* PlayGamesResult::from_cbor / __setstate__ (pybridge.rs:80-92: `serde_cbor::from_slice`), for documents in the form above (what
+ * to_cbor and the reference write; floats of any width and integers are accepted where an f32 is expected).  Two-call pattern:
+ * with metas == counts == recs == NULL the document is validated and counted (*n_games, *n_records); with buffers of those
+ * capacities it is decoded, records getting game_id = their game's and meta = index | terminal flag << 16 like the generator's.
+ * Anything else -> C4_ERR_BAD_ARG with the byte offset in c4_last_error_string() (the reference raises ValueError, pybridge.rs:254-259). */
+int c4_cbor_to_records(const uint8_t* src, uint64_t len, c4_game_metadata* metas, uint32_t* counts, uint64_t cap_games,
+                       c4_sample_rec* recs, uint64_t cap_records, uint64_t* n_games, uint64_t* n_records);
+
+/* PlayGamesResult::split_train_test's permutation (pybridge.rs:110-112: `results.shuffle(&mut StdRng::seed_from_u64(seed))`, rand
+ * 0.10.1): order[i] = index of the game the shuffle leaves at position i of a list of n_games (< 2^32 - 1) games.  The caller then
+ * takes the first round(n_games * train_frac) games as the training set (pybridge.rs:113-119). */
+int c4_shuffle_games(uint64_t seed, uint64_t n_games, uint32_t* order);
 
 /* Root statistics of slot `slot` (MctsGame::root_policy / root_q_with_penalty /
  * root_q_no_penalty / root_visit_count, mcts.rs:248-268).  Synchronises. */

@@ -575,6 +575,78 @@ void c4o_dirichlet(uint64_t game_id, int n_moves, unsigned legal, float alpha, f
 }
 
 /* ------------------------------------------------------------------------------------------
+ * `results.shuffle(&mut rng)` of PlayGamesResult::split_train_test (rust/src/pybridge.rs:110-116):
+ * rand's SliceRandom::shuffle (third-party, rand 0.10.1, source not in /root/reference; restated from
+ * the crate's published algorithm, rand 0.9 src/seq/slice.rs + seq/increasing_uniform.rs +
+ * distr/uniform_int.rs, and pinned by the crate's own `value_stability_slice` vectors in
+ * tests/test_oracle_libm_rng.py):
+ *   shuffle = partial_shuffle(len) (nothing for len <= 1); partial_shuffle(amount): m = len - amount,
+ *   for i in m..len { swap(i, chooser.next_index()) } -- Durstenfeld from the bottom index UP, the index
+ *   for position i drawn from [0, i].  The chooser (IncreasingUniform, slices shorter than 2^32 - 1)
+ *   draws ONE u32 for a whole run of positions: for the next bound n + 1 it takes the longest product
+ *   (n+1)(n+2)...(n+k) that fits a u32, draws chunk = random_range(..product), and hands out
+ *   chunk % (n+1), then chunk /= (n+1), ... the last position of the run gets what is left of chunk.
+ *   random_range(..bound) on u32 = Canon's method with one bias-reducing retry: (hi, lo) = wide product
+ *   of next_u32() and bound; if lo > bound.wrapping_neg() { hi += carry of lo + high word of a second
+ *   next_u32() * bound }.
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t range_u32_below(c4o_next_u32_fn next, void* ctx, uint32_t bound) {
+  uint64_t m = (uint64_t)next(ctx) * bound;
+  uint32_t result = (uint32_t)(m >> 32), lo = (uint32_t)m;
+  if (lo > (uint32_t)(0u - bound)) {
+    uint32_t new_hi = (uint32_t)(((uint64_t)next(ctx) * bound) >> 32);
+    if ((uint64_t)lo + new_hi > 0xFFFFFFFFull) result += 1;
+  }
+  return result;
+}
+
+int c4o_partial_shuffle_with(uint64_t len, uint64_t amount, c4o_next_u32_fn next, void* ctx, uint32_t* items) {
+  if (len >= 0xFFFFFFFFull) return 1; /* the crate switches to per-index random_range on usize there; not restated */
+  const uint64_t m = amount >= len ? 0 : len - amount;
+  uint32_t n = (uint32_t)m, chunk = 0;
+  unsigned chunk_remaining = n == 0 ? 1 : 0;
+  for (uint64_t i = m; i < len; i++) {
+    const uint32_t next_n = n + 1;
+    unsigned next_remaining;
+    if (chunk_remaining >= 1) {
+      next_remaining = chunk_remaining - 1;
+    } else {
+      uint32_t product = next_n, current = next_n + 1;
+      for (;;) {
+        uint64_t p = (uint64_t)product * current;
+        if (p > 0xFFFFFFFFull) break;
+        product = (uint32_t)p;
+        current++;
+      }
+      chunk = range_u32_below(next, ctx, product);
+      next_remaining = (current - next_n) - 1;
+    }
+    uint32_t index;
+    if (next_remaining == 0) {
+      index = chunk;
+    } else {
+      index = chunk % next_n;
+      chunk /= next_n;
+    }
+    chunk_remaining = next_remaining;
+    n = next_n;
+    uint32_t t = items[i]; items[i] = items[index]; items[index] = t;
+  }
+  return 0;
+}
+
+static uint32_t stream_next_cb(void* ctx) { return stream_u32((c4o_stream*)ctx); }
+
+/* order[i] = index of the game that results.shuffle(&mut StdRng::seed_from_u64(seed)) leaves at position i */
+int c4o_shuffle_games(uint64_t seed, uint64_t n_games, uint32_t* order) {
+  for (uint64_t i = 0; i < n_games; i++) order[i] = (uint32_t)i;
+  if (n_games <= 1) return 0;
+  c4o_stream st;
+  stream_init(&st, seed);
+  return c4o_partial_shuffle_with(n_games, n_games, stream_next_cb, &st, order);
+}
+
+/* ------------------------------------------------------------------------------------------
  * MCTS game -- rust/src/mcts.rs:27-413.  Rc<RefCell<Node>> graph restated as an arena of
  * nodes addressed by index; a dead Weak parent link is parent == -1.
  * ---------------------------------------------------------------------------------------- */

@@ -98,6 +98,11 @@ int c4o_sample_move(uint64_t game_id, int n_moves, const float* policy, float te
 
 /* ---- Dirichlet root noise: BUILD EXTENSION (named by BASELINE.json, absent from the reference) ---- */
 void c4o_dirichlet(uint64_t game_id, int n_moves, unsigned legal, float alpha, float* eta7);
+/* rand's SliceRandom::partial_shuffle / shuffle (pybridge.rs:110-116), generic over the source of u32s (tests replay the crate's
+ * vectors through it with rand_pcg::Pcg32), and on StdRng::seed_from_u64(seed) as split_train_test calls it */
+typedef uint32_t (*c4o_next_u32_fn)(void* ctx);
+int c4o_partial_shuffle_with(uint64_t len, uint64_t amount, c4o_next_u32_fn next, void* ctx, uint32_t* items);
+int c4o_shuffle_games(uint64_t seed, uint64_t n_games, uint32_t* order);
 void c4o_self_play_set_dirichlet(float alpha, float epsilon); /* for games created by c4o_self_play; (0,0) = off */
 
 /* ---- one MCTS game (mcts.rs:27-313) ---- */

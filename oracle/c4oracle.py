@@ -77,6 +77,9 @@ class SelfPlayStats(C.Structure):
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_float),
                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float))
 
+NEXT_U32_FN = C.CFUNCTYPE(C.c_uint32, C.c_void_p)
+P = C.POINTER
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -116,6 +119,8 @@ def lib() -> C.CDLL:
         "c4o_weighted_index": (C.c_int, [f32p, C.c_uint32, P(C.c_int)]),
         "c4o_sample_move": (C.c_int, [C.c_uint64, C.c_int, f32p, C.c_float, P(C.c_int)]),
         "c4o_dirichlet": (None, [C.c_uint64, C.c_int, C.c_uint, C.c_float, f32p]),
+        "c4o_partial_shuffle_with": (C.c_int, [C.c_uint64, C.c_uint64, NEXT_U32_FN, C.c_void_p, P(C.c_uint32)]),
+        "c4o_shuffle_games": (C.c_int, [C.c_uint64, C.c_uint64, P(C.c_uint32)]),
         "c4o_self_play_set_dirichlet": (None, [C.c_float, C.c_float]),
         "c4o_game_set_dirichlet": (None, [C.c_void_p, C.c_float, C.c_float]),
         "c4o_game_new": (C.c_void_p, [P(Pos), C.c_uint64, C.c_uint64, C.c_uint64]),
@@ -253,6 +258,23 @@ def apply_temperature(policy: Sequence[float], t: float) -> np.ndarray:
     out = (C.c_float * 7)()
     lib().c4o_apply_temperature(_f7(policy), t, out)
     return np.array(out[:], dtype=np.float32)
+
+
+def partial_shuffle_with(items: Sequence[int], amount: int, next_u32) -> list:
+    """rand's `partial_shuffle(amount)` of `items` (uint32 values) with `next_u32()` as the generator (pybridge.rs:110-116)."""
+    arr = (C.c_uint32 * max(1, len(items)))(*items)
+    cb = NEXT_U32_FN(lambda _ctx: next_u32() & 0xFFFFFFFF)
+    if lib().c4o_partial_shuffle_with(len(items), amount, cb, None, arr):
+        raise ValueError("slice too long")
+    return list(arr[: len(items)])
+
+
+def shuffle_games(seed: int, n_games: int) -> np.ndarray:
+    """order[i] = index of the game `results.shuffle(&mut StdRng::seed_from_u64(seed))` leaves at position i."""
+    out = np.zeros(max(1, n_games), dtype=np.uint32)
+    if lib().c4o_shuffle_games(seed & ((1 << 64) - 1), n_games, out.ctypes.data_as(P(C.c_uint32))):
+        raise ValueError("too many games")
+    return out[:n_games]
 
 
 def weighted_index(w: Sequence[float], u: int) -> int:

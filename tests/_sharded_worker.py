@@ -62,6 +62,12 @@ def main():
         torch.manual_seed(1337)
         net = InferenceNet(ConnectFourNet(ModelConfig(4, 32, 4, 2)), torch.device(device), dtype=torch.bfloat16)
         res = play_games_sharded(reqs, 4096, n_iter, 6.6, 0.01, evaluator=net, device=device, resident_games=256, stats=stats)
+    elif mode == "reclaim":    # n_mcts_iterations beyond the never-reclaimed arena's limit, halves as tight as the library takes, a look every 2nd launch
+        period, n = 2, n_iter
+        half = n + 2 + 8 + 2 * (2 * period * 2 + 16)
+        res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, evaluator=GraphSafeHashEval(), device=device, resident_games=4,
+                                 concurrent_sessions=2, reclaim=True, reclaim_period=period, blocks_per_slot=2 * half, stats=stats)
+        extra = {"reclaim_passes": stats["reclaim_passes"], "reclaim_blocks": stats["reclaim_blocks"]}
     elif mode == "graph2":     # HIP-graph replay, two concurrent sessions per rank
         res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, evaluator=GraphSafeHashEval(), device=device,
                                  resident_games=16, concurrent_sessions=2, stats=stats)

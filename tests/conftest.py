@@ -26,3 +26,15 @@ def _seed():
         torch.manual_seed(1337)
     except Exception:  # pragma: no cover
         pass
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """What the parity tests of this run compared (tests.helpers.evidence): printed after the results, also with -q."""
+    try:
+        from tests.helpers import EVIDENCE
+    except Exception:  # pragma: no cover
+        return
+    if EVIDENCE:
+        terminalreporter.write_line("parity evidence of this run:")
+        for line in EVIDENCE:
+            terminalreporter.write_line("  " + line)

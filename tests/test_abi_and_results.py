@@ -29,7 +29,7 @@ def test_struct_layouts_match_header():
 
     assert C.sizeof(_lib.SampleRec) == 64 == SAMPLE_DTYPE.itemsize
     assert C.sizeof(_lib.GameMetadataC) == 24
-    assert C.sizeof(_lib.Config) == 36          # version 7: + reclaim_period
+    assert C.sizeof(_lib.Config) == 36          # since version 7: + reclaim_period
     assert C.sizeof(_lib.Counters) == 15 * 8 + 8   # version 7: + reclaim_passes, reclaim_blocks
     assert [n for n, *_ in _lib.SampleRec._fields_] == list(SAMPLE_DTYPE.names)
 
@@ -103,12 +103,17 @@ def test_cbor_wire_format_is_serde_cbor_shaped():
     assert bytes([0x1B]) + b"\xff" * 8 in b                                  # u64::MAX as 8-byte uint
     assert bytes([0x66]) + b"policy" + bytes([0x87, 0xF9, 0x38, 0x00, 0xF9, 0x34, 0x00]) in b  # [0.5, 0.25 as f16
     assert bytes([0xFA]) + np.array([np.float32(1) / np.float32(7)], dtype=">f4").tobytes() in b  # 1/7 needs f32
+    from c4a0_amd.results import _py_from_cbor, _py_to_cbor
+    assert b == _py_to_cbor(pgr.results)                                     # the library's encoder == the per-sample Python writer
     back = type(pgr).from_cbor(b)
-    assert back == pgr and back.to_cbor() == b
-    with pytest.raises(ValueError):
-        type(pgr).from_cbor(b[:-3])
-    with pytest.raises(ValueError):
-        type(pgr).from_cbor(b"\x00")
+    assert back._lazy is not None                                            # decoded into records, no objects yet
+    assert back == pgr and back.to_cbor() == b and back.results == _py_from_cbor(b)
+    for bad in (b[:-3], b"\x00", b"", b + b"\x00", b[:40], b.replace(b"policy", b"pol1cy"), b.replace(bytes([0x66]) + b"policy" + bytes([0x87]), bytes([0x66]) + b"policy" + bytes([0x86]))):
+        with pytest.raises(ValueError):
+            type(pgr).from_cbor(bad)
+        with pytest.raises(ValueError):                                      # ... and the checker refuses the same documents
+            _py_from_cbor(bad)
+    assert type(pgr).from_cbor(bytearray(b)) == pgr and type(pgr).from_cbor(memoryview(b)) == pgr
 
 
 def test_pickle_add_unique_split():
@@ -231,28 +236,32 @@ def test_cbor_round_trip_property():
     same bytes, and concatenation commutes with encoding of the parts' results."""
     hyp = pytest.importorskip("hypothesis")
     from hypothesis import given, settings, strategies as st
-    from c4a0_amd.results import GameMetadata, GameResult, PlayGamesResult, Sample
+    from c4a0_amd.results import GameMetadata, GameResult, PlayGamesResult, Sample, _py_from_cbor, _py_to_cbor
 
-    u64 = st.integers(0, (1 << 64) - 1)
-    f32 = st.one_of(st.floats(width=32, allow_nan=False), st.sampled_from([0.5, 0.25, -0.0, 1.0 / 7.0, 65504.0, 2.0 ** -24, float("inf")]))
+    # every unsigned width serde_cbor packs to (1, 2, 3, 5, 9 bytes) and every float class (half normal / subnormal / boundary, f32 only)
+    u64 = st.one_of(st.integers(0, (1 << 64) - 1), st.sampled_from([0, 23, 24, 255, 256, 65535, 65536, (1 << 32) - 1, 1 << 32, (1 << 64) - 1]))
+    f32 = st.one_of(st.floats(width=32, allow_nan=False), st.floats(width=16, allow_nan=False),
+                    st.sampled_from([0.5, 0.25, -0.0, 1.0 / 7.0, 65504.0, 65520.0, 65505.0, 2.0 ** -24, 2.0 ** -25, 3 * 2.0 ** -24, 2.0 ** -14, 1023 * 2.0 ** -24,
+                                     2.0 ** -14 + 2.0 ** -25, 1e-45, float("inf"), float("-inf")]))
 
     @st.composite
     def samples(draw):
-        mask = draw(st.integers(0, (1 << 42) - 1))
-        value = draw(st.integers(0, (1 << 42) - 1)) & mask
+        mask = draw(st.one_of(st.integers(0, (1 << 42) - 1), u64))
+        value = draw(st.integers(0, (1 << 64) - 1)) & mask
         pol = np.array(draw(st.lists(f32, min_size=7, max_size=7)), dtype=np.float32)
         return Sample(mask, value, pol, np.float32(draw(f32)), np.float32(draw(f32)))
 
     games = st.builds(lambda a, b, c, ss: GameResult(GameMetadata(a, b, c), ss), u64, u64, u64, st.lists(samples(), max_size=4))
 
-    @settings(max_examples=60, deadline=None)
+    @settings(max_examples=120, deadline=None)
     @given(st.lists(games, max_size=4), st.lists(games, max_size=3))
     def check(g1, g2):
         a, b = PlayGamesResult(g1), PlayGamesResult(g2)
         for r in (a, b, a + b):
             enc = r.to_cbor()
+            assert enc == _py_to_cbor(r.results)            # native encoder (on records) == per-sample Python writer
             back = PlayGamesResult.from_cbor(enc)
-            assert back.to_cbor() == enc
+            assert back.to_cbor() == enc and back.results == _py_from_cbor(enc)
             assert len(back.results) == len(r.results)
             for x, y in zip(back.results, r.results):
                 assert (x.metadata.game_id, x.metadata.player0_id, x.metadata.player1_id) == \
@@ -265,6 +274,108 @@ def test_cbor_round_trip_property():
                     assert np.float32(s.q_no_penalty).tobytes() == np.float32(t.q_no_penalty).tobytes()
 
     check()
+
+
+def test_native_decoder_accepts_what_the_python_checker_accepts():
+    """Where an f32 is expected serde's visitor takes any number: halves, singles, doubles and integers.  A document written with
+    those widths by hand decodes to the same records through the library and through the Python checker, NaN payloads collapse to
+    the quiet NaN serde_cbor writes (f9 7e00), and the record bookkeeping (game_id copy, index | terminal flag) is the generator's."""
+    import struct
+    from c4a0_amd.results import PlayGamesResult, _K, _cbor_uint, _py_from_cbor
+
+    def sample(mask, value, floats):
+        assert len(floats) == 9
+        return b"".join([_cbor_uint(5, 4), _K["pos"], _cbor_uint(5, 2), _K["mask"], _cbor_uint(0, mask), _K["value"], _cbor_uint(0, value),
+                         _K["policy"], _cbor_uint(4, 7)] + floats[:7] + [_K["q_penalty"], floats[7], _K["q_no_penalty"], floats[8]])
+
+    f16 = lambda x: b"\xf9" + struct.pack(">e", x)
+    f32 = lambda x: b"\xfa" + struct.pack(">f", x)
+    f64 = lambda x: b"\xfb" + struct.pack(">d", x)
+    fl = [f16(0.5), f32(0.1), f64(0.1), _cbor_uint(0, 3), _cbor_uint(0, 1 << 40), f16(6e-8), f64(1e300), b"\xf9\x7e\x01", f32(float("-inf"))]
+    doc = b"".join([_cbor_uint(5, 1), _K["results"], _cbor_uint(4, 1), _cbor_uint(5, 2), _K["metadata"], _cbor_uint(5, 3),
+                    _K["game_id"], _cbor_uint(0, 77), _K["player0_id"], _cbor_uint(0, 1), _K["player1_id"], _cbor_uint(0, 2),
+                    _K["samples"], _cbor_uint(4, 2), sample(5, 1, fl), sample(7, 2, fl[::-1])])
+    got = PlayGamesResult.from_cbor(doc)
+    recs, counts = got.to_records()
+    assert counts.tolist() == [2] and recs["game_id"].tolist() == [77, 77] and recs["meta"].tolist() == [0, 1 | (1 << 16)]
+    want = _py_from_cbor(doc)
+    with np.errstate(over="ignore"):
+        for s, t in zip(got.results[0].samples, want[0].samples):
+            assert (s.mask, s.value) == (t.mask, t.value)
+            assert np.array_equal(s.policy.view(np.uint32) & 0xFFC00000, t.policy.view(np.uint32) & 0xFFC00000)   # NaN payload bits aside
+            assert np.array_equal(s.policy[~np.isnan(s.policy)], t.policy[~np.isnan(t.policy)])
+    assert np.isinf(recs["policy"][0][6]) and recs["policy"][0][3] == 3.0 and recs["policy"][0][4] == np.float32(1 << 40)
+    assert np.isnan(recs["q_penalty"][0]) and recs["q_no_penalty"][0] == -np.inf
+    # NaN / infinities are written as serde_cbor writes them
+    enc = got.to_cbor()
+    assert b"\xf9\x7e\x00" in enc and b"\xf9\xfc\x00" in enc and b"\xf9\x7c\x00" in enc
+
+
+def test_codec_throughput_keeps_up_with_the_generator():
+    """the generator emits ~0.5 M samples per second of play; pickling a result (src/c4a0/training.py:62-63:
+    `pickle.dump(games, f)` = __getstate__ = to_cbor) must not be slower than playing it.  Bound: >= 1 M samples/s each way on
+    whatever core runs this test (the library does 5-30 M; the per-sample Python writer it replaced did 0.025 M)."""
+    import time
+    from c4a0_amd.results import PlayGamesResult, results_from_records
+    from c4a0_amd.session import SAMPLE_DTYPE
+
+    rng = np.random.default_rng(5)
+    g = 4096
+    counts = rng.integers(8, 30, g).astype(np.uint32)
+    n = int(counts.sum())
+    recs = np.zeros(n, dtype=SAMPLE_DTYPE)
+    recs["mask"] = rng.integers(0, 1 << 42, n, dtype=np.uint64)
+    recs["value"] = recs["mask"] & rng.integers(0, 1 << 42, n, dtype=np.uint64)
+    recs["policy"] = rng.integers(0, 100, (n, 7)).astype(np.float32) / np.float32(100)
+    recs["q_penalty"] = rng.random(n, dtype=np.float32)
+    recs["q_no_penalty"] = np.sign(recs["q_penalty"])
+    ids = np.stack([np.arange(g, dtype=np.uint64), np.zeros(g, np.uint64), np.ones(g, np.uint64)], 1)
+    res = results_from_records(ids, recs, counts)
+    res.to_cbor()                                           # first call: library load
+    t0 = time.perf_counter()
+    blob = pickle.dumps(res)
+    t1 = time.perf_counter()
+    back = pickle.loads(blob)
+    t2 = time.perf_counter()
+    assert back == res and back._lazy is not None and res._lazy is not None
+    assert n / (t1 - t0) > 1e6 and n / (t2 - t1) > 1e6, (n, t1 - t0, t2 - t1)
+    assert (res + back).to_cbor() == PlayGamesResult.from_cbor(res.to_cbor()).__add__(back).to_cbor()   # record-form concatenation
+    assert len(res + back) == 2 * g
+
+
+def test_split_train_test_is_rands_slice_shuffle():
+    """pybridge.rs:110-116: `results.shuffle(&mut StdRng::seed_from_u64(seed))`, then the first round(len * frac) games train.  The
+    library's permutation (c4_shuffle_games) equals the oracle's restatement, which the rand crate's own vectors pin
+    (tests/test_oracle_libm_rng.py); lazy and object-built results split identically and `self` keeps its order and its form."""
+    from c4a0_amd.results import GameMetadata, GameResult, PlayGamesResult, Sample, results_from_records, shuffled_game_order
+    from c4a0_amd.session import SAMPLE_DTYPE
+    from oracle import c4oracle as O
+
+    for seed in (0, 1, 1337, (1 << 64) - 1, 0xDEADBEEFCAFE):
+        for n in (0, 1, 2, 3, 12, 13, 14, 100, 1000, 4097, 70001):
+            got = shuffled_game_order(n, seed)
+            assert np.array_equal(got, O.shuffle_games(seed, n).astype(np.int64)), (seed, n)
+    rng = np.random.default_rng(1)
+    counts = rng.integers(0, 5, 37).astype(np.uint32)
+    recs = np.zeros(int(counts.sum()), dtype=SAMPLE_DTYPE)
+    recs["mask"] = np.repeat(np.arange(37, dtype=np.uint64), counts.astype(np.int64))      # every sample carries its game's index
+    recs["policy"] = rng.random((len(recs), 7), dtype=np.float32)
+    ids = np.stack([np.arange(37, dtype=np.uint64)] * 3, 1)
+    lazy = results_from_records(ids, recs, counts)
+    objs = PlayGamesResult(results_from_records(ids, recs, counts).results)
+    for frac, seed in ((0.5, 1337), (0.8, 0), (0.0, 5), (1.0, 5)):
+        order = O.shuffle_games(seed, 37).tolist()
+        n_train = int(np.floor(float(np.float32(37) * np.float32(frac)) + 0.5))
+        want_train = [g for g in order[:n_train] for _ in range(counts[g])]
+        want_test = [g for g in order[n_train:] for _ in range(counts[g])]
+        for res in (lazy, objs):
+            tr, te = res.split_train_test(frac, seed)
+            assert [s.mask for s in tr] == want_train and [s.mask for s in te] == want_test
+        a, b = lazy.split_train_test(frac, seed), objs.split_train_test(frac, seed)
+        assert a[0] == b[0] and a[1] == b[1]
+    assert lazy._lazy is not None and [r.metadata.game_id for r in objs.results] == list(range(37))
+    # negative seeds never reach the reference (PyO3 extracts a u64); the low 64 bits are used here
+    assert np.array_equal(shuffled_game_order(20, -1), shuffled_game_order(20, (1 << 64) - 1))
 
 
 def test_merge_parts_restores_request_order_numpy_and_torch():
@@ -343,7 +454,7 @@ def test_gemm_block_to_tile_map_is_a_bijection_for_every_grid():
     import ctypes as C
     from c4a0_amd import _lib
     L = _lib.lib()
-    shapes = [(128, 192), (256, 192), (64, 192), (128, 96), (64, 96), (96, 96), (64, 64), (192, 192), (96, 64)]
+    shapes = [(128, 192), (256, 192), (64, 192), (128, 96), (64, 96), (96, 96), (64, 64), (192, 192), (96, 64), (192, 96), (96, 192)]   # the last two: configs 54-59 (round 5)
     for bm, bn in shapes:
         for n in [192 * i for i in (1, 2, 3, 4, 7, 8, 14, 16, 28)] + [2688 * 2]:
             if n % bn:

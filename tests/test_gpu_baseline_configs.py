@@ -135,6 +135,8 @@ def test_config4_4096_games_n800_hash_evaluator_structure_and_oracle_subset():
     sub = sorted(np.random.default_rng(4).choice(ids, 128, replace=False).tolist())   # round 5: 128 games through the oracle (16 before)
     want, _ = O.self_play([(g, 0, 0) for g in sub], 64, n_iter, 6.6, 0.01, "hash", n_threads=8)
     assert _subset(recs, sub) == oracle_samples_by_game(want)
+    from tests.helpers import evidence
+    evidence(f"config 4 tree shape (4 096 games, n = 800, hash evaluator): {len(recs)} samples structurally checked, {len(sub)} games == oracle bit for bit")
 
 
 def test_config4_4096_games_n800_8x64_network_t3_replay():
@@ -149,6 +151,8 @@ def test_config4_4096_games_n800_8x64_network_t3_replay():
     assert ctr["games_done"] == n and ctr["error"] == 0
     _check_structure(recs, counts, ids)
     assert _subset(recs, log_slots) == _oracle_replay(seq, [(g, ids[g]) for g in log_slots], n_iter)
+    from tests.helpers import evidence
+    evidence(f"config 4 (4 096 games, n = 800, 8x64 bf16 network): {len(recs)} samples structurally checked, {len(log_slots)} games replayed leaf by leaf by the oracle (T3)")
 
 
 @pytest.mark.parametrize("dirichlet", [None, (0.3, 0.25)])
@@ -166,6 +170,8 @@ def test_config5_per_rank_8192_games_n200_8x64_network_plain_and_dirichlet(diric
     _check_structure(recs, counts, ids)
     sub = [ids[g] for g in log_slots]
     assert _subset(recs, sub) == _oracle_replay(seq, [(g, ids[g]) for g in log_slots], n_iter, dirichlet or (0.0, 0.0))
+    from tests.helpers import evidence
+    evidence(f"config 5 per-rank share (8 192 games, n = 200, 8x64 bf16 network, Dirichlet {dirichlet}): {len(recs)} samples structurally checked, {len(sub)} games replayed by the oracle (T3)")
 
 
 def test_config3_shard_pattern_equals_the_single_rank_run():
@@ -219,3 +225,5 @@ def test_bench_configuration_graph_two_sessions_equals_eager_and_oracle():
     got, got_counts = res.to_records()
     assert np.array_equal(got_counts, want_counts)
     assert got.tobytes() == want.tobytes()
+    from tests.helpers import evidence
+    evidence(f"bench configuration (config 2 network, 2 x 2 048 slots, 8 192 games): paired-graph play_games == two eager sessions byte for byte ({len(got)} samples), {len(log_slots)} games replayed by the oracle (T3)")

@@ -75,10 +75,12 @@ def test_config2_size_properties_placement_independence_and_oracle_subset():
            {k: ctr2[k] for k in ("sims", "select_levels", "backup_nodes", "expansions", "moves")}
     # a random subset replayed by the oracle, bit for bit
     rng = np.random.default_rng(1)
-    sub = sorted(rng.choice(n, 48, replace=False).tolist())
-    want, _ = O.self_play([(g, 0, 0) for g in sub], 64, 100, 6.6, 0.01, "hash")
+    sub = sorted(rng.choice(n, 128, replace=False).tolist())          # round 6: 128 games through the oracle (48 before), 8 oracle threads
+    want, _ = O.self_play([(g, 0, 0) for g in sub], 64, 100, 6.6, 0.01, "hash", n_threads=8)
     got = samples_by_game(recs[np.isin(recs["game_id"], np.array(sub, dtype=np.uint64))])
     assert got == oracle_samples_by_game(want)
+    from tests.helpers import evidence
+    evidence(f"config 2 (4 096 games, n = 100, hash evaluator): {len(recs)} samples structurally checked, 2 placements byte-identical, {len(sub)} games == oracle bit for bit")
     # every game needs at least 7 moves x (n - retained) sims
     assert ctr["sims"] / n > 300 and 8 <= len(recs) / n <= 43
 

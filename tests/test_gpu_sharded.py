@@ -82,6 +82,49 @@ def test_rccl_world_size_one_equals_play_games(tmp_path, mode, n_games, n_iter):
     _assert_equals_oracle(single, reqs, n_iter)
 
 
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
+def test_sharded_play_with_reclaimed_arenas_beyond_the_old_search_limit(tmp_path, backend, world):
+    """`play_games_sharded` takes every keyword `play_games` takes (its table is read off `_play`'s signature),
+    here reclaim / reclaim_period / blocks_per_slot: n_mcts_iterations = 1 600 (the never-reclaimed arena stops at 1 523) with the
+    tightest halves the library accepts, two ranks over gloo and one over RCCL; the merged result is the oracle's, sample for
+    sample, and the arenas really were reclaimed on every rank."""
+    n_games, n_iter, port = 6, 1600, str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_sharded_worker.py"), str(r), str(world), port,
+                               str(tmp_path), str(n_games), str(n_iter), "reclaim", backend], env=env, cwd=ROOT) for r in range(world)]
+    import numpy as np
+    from c4a0_amd import GameMetadata, PlayGamesResult
+    from oracle import c4oracle as O
+    from tests.helpers import oracle_samples_by_game
+
+    reqs = [GameMetadata(1000 + 7 * i, 0, 0) for i in range(n_games)]
+    ora, _ = O.self_play([(r.game_id, 0, 0) for r in reqs], 64, n_iter, 6.6, 0.01, "hash")
+    want = oracle_samples_by_game(ora)
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    for r in range(world):
+        got = pickle.load(open(tmp_path / f"rank{r}.pkl", "rb"))
+        assert got["allgather"]["backend"] == backend and got["reclaim_passes"] > n_games // world, got["reclaim_passes"]
+        res = PlayGamesResult.from_cbor(got["cbor"])
+        assert [g.metadata.game_id for g in res.results] == [q.game_id for q in reqs]
+        for g in res.results:
+            mine = [(s.mask, s.value, np.asarray(s.policy, dtype=np.float32).tobytes(), np.float32(s.q_penalty).tobytes(),
+                     np.float32(s.q_no_penalty).tobytes()) for s in g.samples]
+            assert mine == want[g.metadata.game_id], f"rank {r} game {g.metadata.game_id}"
+
+
+def test_sharded_keywords_are_play_games_keywords():
+    """The keyword table of play_games_sharded IS _play's signature: every keyword-only argument of play_games (except the
+    evaluator forms and stats, which the sharded entry point has itself) is accepted, anything else is refused by name."""
+    import inspect
+    from c4a0_amd.api import _play, play_games
+
+    play_kw = {k for k, v in inspect.signature(play_games).parameters.items() if v.kind is inspect.Parameter.KEYWORD_ONLY} - {"evaluator", "stats"}
+    own = set(inspect.signature(_play).parameters) - {"reqs", "max_nn_batch_size", "n_mcts_iterations", "c_exploration", "c_ply_penalty",
+                                                      "py_eval_pos_cb", "evaluator", "stats", "on_device"}
+    assert play_kw == own, play_kw ^ own
+
+
 def _check_bench_line(r, n_gpus):
     import json
 

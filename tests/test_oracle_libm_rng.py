@@ -194,6 +194,65 @@ def test_weighted_index_value_stability_vector_of_the_rand_crate():
     assert out == [2, 2, 1, 3, 2, 1, 3, 3, 2, 1]
 
 
+def test_slice_shuffle_value_stability_vectors_of_the_rand_crate():
+    """rand's own `value_stability_slice` test (rand 0.9 src/seq/slice.rs; third-party source not in /root/reference, vector
+    quoted from the published crate): with `crate::test::rng(414)`, `[0, 1, .., 12].shuffle(&mut r)` gives
+    [5, 11, 0, 8, 7, 12, 6, 4, 9, 3, 1, 2, 10], and on the SAME generator `[0..=12].partial_shuffle(&mut r, 6)` then returns
+    ([7, 12, 6, 8, 1, 9], [0, 11, 2, 3, 4, 5, 10]).  Thirteen elements: positions 1..11 share the first index chunk (one u32 below
+    12!), position 12 opens the second (below 13 * .. * 19), and the partial shuffle starts its chooser at n = 7 -- so the vectors
+    pin the direction of the walk, the chunk bounds, the % / order of peeling, and `random_range(..bound)` on u32 (Canon's method:
+    both results depend on the high word of next_u32 * bound).  This is what split_train_test's permutation rests on
+    (pybridge.rs:110-112)."""
+    rng = _Pcg32(414, 11634580027462260723)
+    assert O.partial_shuffle_with(list(range(13)), 13, rng.next_u32) == [5, 11, 0, 8, 7, 12, 6, 4, 9, 3, 1, 2, 10]
+    out = O.partial_shuffle_with(list(range(13)), 6, rng.next_u32)
+    assert out[7:] == [7, 12, 6, 8, 1, 9] and out[:7] == [0, 11, 2, 3, 4, 5, 10]
+
+
+def test_shuffle_games_is_a_permutation_and_a_function_of_the_seed():
+    """c4o_shuffle_games = the same walk on StdRng::seed_from_u64(seed) (ChaCha12 words in order): a permutation, reproducible,
+    seed-dependent, identity for fewer than two games (shuffle() returns before drawing), and a prefix property of the chooser:
+    the first chunk serves positions 1..11 whatever the length, so lists of 12 and 13 games agree on where games 0..11 went
+    relative to each other only up to the last swap -- checked against a plain-Python walk fed by the oracle's own ChaCha words."""
+    for n in (0, 1):
+        assert O.shuffle_games(99, n).tolist() == list(range(n))
+    a, b = O.shuffle_games(1337, 1000), O.shuffle_games(1337, 1000)
+    assert a.tolist() == b.tolist() and sorted(a.tolist()) == list(range(1000)) and a.tolist() != O.shuffle_games(1338, 1000).tolist()
+    # an independent walk in Python over the same word stream
+    for seed, n in ((0, 2), (1337, 13), (1337, 14), ((1 << 64) - 1, 300), (42, 5000)):
+        key = O.seed_key(seed)
+        words, blk = [], 0
+
+        def next_u32():
+            nonlocal blk
+            if not words:
+                words.extend(O.chacha_block(key, blk, 12))
+                blk += 1
+            return words.pop(0)
+
+        def below(bound):
+            m = next_u32() * bound
+            hi, lo = m >> 32, m & 0xFFFFFFFF
+            if lo > ((-bound) & 0xFFFFFFFF):
+                hi += (lo + ((next_u32() * bound) >> 32)) >> 32
+            return hi
+
+        items, chunk, left = list(range(n)), 0, 1
+        for i in range(n):
+            if left == 0:
+                product, nxt = i + 1, i + 2
+                while product * nxt <= 0xFFFFFFFF:
+                    product, nxt = product * nxt, nxt + 1
+                chunk, left = below(product), nxt - (i + 1)
+            left -= 1
+            if left == 0:
+                j = chunk
+            else:
+                j, chunk = chunk % (i + 1), chunk // (i + 1)
+            items[i], items[j] = items[j], items[i]
+        assert O.shuffle_games(seed, n).tolist() == items, (seed, n)
+
+
 def test_weighted_index_semantics():
     # x = u01 * scale; index = #cumulative weights <= x  (partition_point)
     w = [0.25, 0.25, 0.0, 0.25, 0.0, 0.0, 0.25]

@@ -19,6 +19,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20260002)
 t0, n_jobs, n_games_total, n_errs, n_cb_jobs = time.time(), 0, 0, 0, 0
 n_reclaimed_jobs = 0
+n_dirichlet_jobs = 0
 
 
 def player(model_id, x):      # every "model" prefers other columns (the oracle calls the same function)
@@ -119,6 +120,8 @@ while time.time() - t0 < budget:
     c_expl = rng.choice([0.0, 0.5, 1.4, 4.0, 6.6, 25.0])
     c_ply = rng.choice([0.0, 0.001, 0.01, 0.02])
     dirichlet = rng.choice([None, None, (0.3, 0.25), (1.0, 0.5), (0.05, 0.1)])
+    if "FUZZ_DIRICHLET_SHARE" in os.environ:   # (FUZZ_DIRICHLET_SHARE=1: every tree job with root noise)
+        dirichlet = rng.choice([(0.3, 0.25), (1.0, 0.5), (0.05, 0.1)]) if rng.random() < float(os.environ["FUZZ_DIRICHLET_SHARE"]) else None
     cache = rng.choice([0, 0, 1024, 1 << 16])
     one_sim = rng.random() < 0.2
     graph = rng.random() < 0.4
@@ -159,8 +162,9 @@ while time.time() - t0 < budget:
         continue
     assert ctr["error"] == 0 and ctr["games_done"] == len(ids), (cfg, ctr)
     n_reclaimed_jobs += 1 if ctr["reclaim_passes"] else 0
+    n_dirichlet_jobs += 1 if dirichlet else 0
     assert got == oracle_samples_by_game(want), cfg
     n_jobs += 1
     n_games_total += len(ids)
-print(f"fuzz parity ok: {n_jobs} jobs ({n_cb_jobs} of them through the numpy callback, one or several models; {n_fused_jobs} with the bf16 network, fused graph path vs eager; {n_reclaimed_jobs} on arenas reclaimed during play), {n_games_total} games in {time.time() - t0:.0f} s; "
+print(f"fuzz parity ok: {n_jobs} jobs ({n_cb_jobs} of them through the numpy callback, one or several models; {n_fused_jobs} with the bf16 network, fused graph path vs eager; {n_reclaimed_jobs} on arenas reclaimed during play; {n_dirichlet_jobs} with Dirichlet noise), {n_games_total} games in {time.time() - t0:.0f} s; "
       f"{n_errs} more jobs ended in the same panic on both sides")

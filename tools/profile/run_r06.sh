@@ -1,17 +1,21 @@
 #!/bin/bash
-# Round-5 evidence for profiles/: run on the GPU box from the repo root (gpurun -- 'bash tools/profile/run_r05.sh').
-# Every step is bounded by its own timeout; the summaries land under gpurun_out/r05p and are copied into profiles/ by hand.
-O=gpurun_out/r05p; mkdir -p $O; export TMPDIR=/tmp
-timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+# Round-6 evidence for profiles/: run on the GPU box from the repo root (gpurun -- 'bash tools/profile/run_r06.sh').
+# Every step is bounded by its own timeout; the summaries land under gpurun_out/r06p and are copied into profiles/ by hand.
+# Counter passes (--pmc) are their own runs, with --kernel-trace only (never with --stats / other trace domains).
+O=gpurun_out/r06p; mkdir -p $O; export TMPDIR=/tmp
+timeout 600 python bench.py --steps 20 --warmup 1 > $O/bench.json 2> $O/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 1 --no-cpu-baseline --no-other-configs > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv; rm -rf $O/stats
+# HBM traffic of the tree kernel: FETCH_SIZE and WRITE_SIZE, one pass each, of the bench command; summarised for the stand-alone
+# c4_step_kernel (the 300 instrumented launches) and for c4_out_step_kernel (the last 300 launches = the event-bracketed rounds)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --rounds-per-step 64 --preroll 640 --instrumented-steps 300 --no-cpu-baseline --no-other-configs > $O/pmc_$c.json 2> $O/pmc_$c.err
-  python tools/profile/summarize_pmc.py $O/pmc_$c c4_step_kernel 20 > $O/traffic_$c.json   # the 300 instrumented launches (the timed region runs the step inside c4_out_step_kernel)
+  python tools/profile/summarize_pmc.py $O/pmc_$c c4_step_kernel 20 > $O/traffic_$c.json
+  python tools/profile/summarize_pmc.py $O/pmc_$c c4_out_step_kernel -300 > $O/traffic_fused_$c.json
   rm -rf $O/pmc_$c
 done
 timeout 300 python tools/tree_roofline.py --games 2048,4096,16384,65536,131072 > $O/tree_sweep.json 2> $O/tree_sweep.err
-# the step kernel's instruction and wait counters re-collected on the CURRENT kernel (last taken in round 2)
+# the step kernel's instruction and issue counters on the CURRENT kernel (two passes of 8 counters each, per launch size)
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY"
 SQ2="SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 for g in 65536 2048; do

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-launch averages of rocprofv3 --pmc counters for one kernel.
 
-    python tools/profile/summarize_pmc.py <rocprof output dir> [kernel substring] [skip first N dispatches]
+    python tools/profile/summarize_pmc.py <rocprof output dir> [kernel substring] [skip first N dispatches | -N = keep only the last N]
 """
 import collections
 import csv
@@ -20,7 +20,7 @@ for row in csv.DictReader(open(fs[0])):
     did = row["Dispatch_Id"]
     if did not in order:
         order.append(did)
-keep = set(order[skip:])
+keep = set(order[skip:])   # (a negative N keeps the last N: Python's slice)
 for row in csv.DictReader(open(fs[0])):
     if kern in row["Kernel_Name"] and row["Dispatch_Id"] in keep:
         acc[row["Counter_Name"]] += float(row["Counter_Value"])

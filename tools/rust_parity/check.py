@@ -2,15 +2,13 @@
 """Compares the output of the reference-side test (parity_kit.rs, run with cargo in the reference's rust/ directory)
 with what this repository's restatements answer.
 
-    python tools/rust_parity/check.py out.txt [--live] [--strict-split]
+    python tools/rust_parity/check.py out.txt [--live]
 
 Default: against the committed `expected.txt`.  --live: the expected lines are recomputed now from the oracle
 (oracle/libc4oracle.so) and c4a0_amd/results.py instead of read from the file.
 
-Exit code 0 when every `rng`, `move` and `cbor` line agrees.  `split` lines are reported but do not fail the check
-unless --strict-split: this repository's `split_train_test` uses a seeded numpy permutation, a stated deviation
-(the reference's own test only requires determinism, tests/c4a0_tests/pybridge_test.py:22-39); the train
-COUNT must agree in any case."""
+Exit code 0 when every `rng`, `move`, `cbor` and `split` line agrees (the split's train count AND game order:
+`split_train_test` restates rand's slice shuffle since round 6, include/c4a0_hip.h c4_shuffle_games)."""
 import os
 import sys
 
@@ -46,7 +44,7 @@ def main(argv):
     if got.get("version") != want.get("version"):
         print(f"kit version mismatch: output says {got.get('version')!r}, expected {want.get('version')!r}")
         return 2
-    bad = deviating = ok = 0
+    bad = ok = 0
     for key, w in want.items():
         if key == "version":
             continue
@@ -57,9 +55,6 @@ def main(argv):
             bad += 1
         elif g == w:
             ok += 1
-        elif kind == "split" and "--strict-split" not in argv and g.split(" ")[0] == w.split(" ")[0]:
-            print(f"deviation (stated: seeded numpy permutation here, rand's slice shuffle there)  {key}\n    reference: {g}\n    here:      {w}")
-            deviating += 1
         else:
             what = {"rng": "StdRng::seed_from_u64 output words", "move": "tempered policy / sampled column", "cbor": "serde_cbor bytes",
                     "split": "train count or order"}[kind]
@@ -68,7 +63,7 @@ def main(argv):
     extra = [k for k in got if k not in want]
     for k in extra:
         print(f"UNEXPECTED line in the output: {k}")
-    print(f"{ok} lines agree, {deviating} stated deviations, {bad + len(extra)} failures")
+    print(f"{ok} lines agree, {bad + len(extra)} failures")
     return 0 if bad == 0 and not extra else 1
 
 

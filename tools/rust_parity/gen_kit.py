@@ -6,7 +6,8 @@ Why: the reference samples every move with rand 0.10.1 (`StdRng::seed_from_u64`,
 rust/src/mcts.rs:214-222, rust/Cargo.lock), serialises results with serde_cbor 0.11.2 (rust/src/pybridge.rs:73-92)
 and splits them with rand's slice shuffle (pybridge.rs:110-120).  None of these crates' sources is in
 /root/reference and the build container has no Rust toolchain, so the restatements (oracle/c4_oracle.c
-c4o_seed_from_u64 / c4o_chacha_block / c4o_weighted_index / c4o_sample_move, c4a0_amd/results.py) are pinned by
+c4o_seed_from_u64 / c4o_chacha_block / c4o_weighted_index / c4o_sample_move / c4o_shuffle_games, the library's c4_records_to_cbor
+and c4_shuffle_games behind c4a0_amd/results.py) are pinned by
 the crates' published vectors of EARLIER versions only.  A maintainer with cargo closes the gap in
 one command -- see README.md beside this file.
 
@@ -83,7 +84,8 @@ CBOR_GAMES = [
          samples=[(POLICIES["peaked"], 1.0e-8, 0.333333343267), (POLICIES["edge"], -0.123456789, 2.0 ** -24)]),
 ]
 
-SPLITS = [(n, frac, seed) for n in (1, 2, 5, 10, 37) for frac, seed in ((0.5, 1337), (0.8, 0))]
+# 13 and 14 games: the last position of the first index chunk (12!) and the first of the second; 100: several chunks
+SPLITS = [(n, frac, seed) for n in (1, 2, 5, 10, 13, 14, 37, 100) for frac, seed in ((0.5, 1337), (0.8, 0))] + [(37, 0.5, U64)]
 
 
 def _make_move(mask, value, col):   # c4r.rs:58-72 + invert :125-129
