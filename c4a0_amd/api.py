@@ -23,11 +23,15 @@ from .results import GameMetadata, PlayGamesResult, results_from_records
 from .session import DeviceEvaluator, DeviceSession
 
 # Games advanced in lock-step per round when the caller does not say (`resident_games=`).  Two forces (MI355X, BASELINE config 2's
-# network, a 40 960-game job, profiles/r06_whole_call.txt): more resident games make a round more efficient -- 37.6 / 41.6 / 43.9 k
-# game-rounds per ms at 4 096 / 8 192 / 16 384 slots (fuller GEMM grids, a step kernel further from its latency floor) -- but the
-# job's TAIL, the rounds after the last request has been started, when finished slots stay empty, grows with them: 0.24 / 0.34 /
-# 0.53 s; with every game resident at once the whole job is tail (1.8 s against 1.57).  A quarter of the job, between 4 096 and
-# 16 384 slots, sits in the flat optimum; the tree arenas of the slots are kept below a quarter of the device's free memory.
+# network, profiles/r06_whole_call.txt): more resident games make a round more efficient (fuller GEMM grids, a step kernel further
+# from its latency floor) but the job's TAIL -- the rounds after the last request has been started, when finished slots stay empty
+# and a round cannot get shorter than its five launches' latency, ~60 us -- grows with them.  Whole calls, seconds:
+#     games    4 096 slots   8 192    16 384    (10 240: 1.633 -- 5 120 rows per session are 1.25 waves of tower workgroups)
+#    16 384      0.770       0.770      -
+#    40 960      1.603       1.519     1.521
+#    81 920      3.048       2.836     2.801
+# So: the largest of 4 096 / 8 192 / 16 384 (whole waves of workgroups for every kernel of the evaluator) that the job fills at least
+# four times over, and never more tree arena than a quarter of the device's free memory.
 DEFAULT_RESIDENT_GAMES = 4096
 MAX_DEFAULT_RESIDENT_GAMES = 16384
 
@@ -35,13 +39,16 @@ MAX_DEFAULT_RESIDENT_GAMES = 16384
 def default_resident_games(n_games: int, n_mcts_iterations: int, graph_safe: bool, device=None) -> int:
     if n_games <= DEFAULT_RESIDENT_GAMES or not graph_safe:   # callback / multi-model modes: a host round trip per round, rows are not the limit
         return min(n_games, DEFAULT_RESIDENT_GAMES)
-    want = min(MAX_DEFAULT_RESIDENT_GAMES, max(DEFAULT_RESIDENT_GAMES, -(-n_games // 4 // 1024) * 1024))
+    want = DEFAULT_RESIDENT_GAMES
+    while want < MAX_DEFAULT_RESIDENT_GAMES and n_games >= 8 * want:
+        want *= 2
     # arena bytes per slot (include/c4a0_hip.h c4_config.blocks_per_slot): 43 n + 8 blocks of 128 bytes, or two reclaimed halves above n = 1 000
     n = max(1, n_mcts_iterations)
     per_slot = 128 * ((43 * n + 8) if n <= 1000 else 2 * (5 * n // 2 + 554))
     try:
         free, _total = torch.cuda.mem_get_info(device)
-        want = min(want, max(DEFAULT_RESIDENT_GAMES, int(free // 4 // per_slot) // 1024 * 1024))
+        while want > DEFAULT_RESIDENT_GAMES and want * per_slot > free // 4:
+            want //= 2
     except Exception:
         pass
     return want
@@ -328,12 +335,12 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
             steps = max(run_sessions(sessions, evaluator, steps_per_graph=steps_per_graph, phases=phases, tail_steps_per_graph=tail_steps_per_graph))
         elif evaluator is None:
             ev = _CallbackEvaluator(sessions[0], py_eval_pos_cb, max_nn_batch_size, reqs[:, 1], reqs[:, 2])
-            steps = sessions[0].run(ev, poll_every=4)   # the completion probe every 4th step: at most 3 idle steps at the very end
+            steps = sessions[0].run(ev, poll_every=4, phases=phases)   # the completion probe every 4th step: at most 3 idle steps at the very end
         elif multi:
-            steps = sessions[0].run(_MultiModelEvaluator(sessions[0], evaluator))
+            steps = sessions[0].run(_MultiModelEvaluator(sessions[0], evaluator), phases=phases)
         else:
             # a c4a0_amd.nn.InferenceNet is pure device code: replay it and the step kernel from a HIP graph
-            steps = sessions[0].run(evaluator, steps_per_graph=steps_per_graph)
+            steps = sessions[0].run(evaluator, steps_per_graph=steps_per_graph, phases=phases)
         t_drain0 = time.perf_counter()
         pieces = []
         merge_on_device = on_device or parts > 1   # several sessions: interleave their records on the device, ONE transfer to the host

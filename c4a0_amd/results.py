@@ -44,12 +44,14 @@ def terminal_state(mask: int, value: int) -> int:
     return 0
 
 
+_REV7 = [int(f"{i:07b}"[::-1], 2) for i in range(128)]   # a row's 7 cells mirrored
+
+
 def flip_h_bits(x: int) -> int:
     """Mirror the 7 columns of every row (c4r.rs:289-299)."""
-    out = 0
-    for col in range(7):
-        out |= ((x >> col) & _COL0) << (6 - col)
-    return out
+    r = _REV7
+    return (r[x & 127] | r[(x >> 7) & 127] << 7 | r[(x >> 14) & 127] << 14 | r[(x >> 21) & 127] << 21
+            | r[(x >> 28) & 127] << 28 | r[(x >> 35) & 127] << 35)
 
 
 class GameMetadata:
@@ -94,13 +96,15 @@ class Sample:
         return out
 
     def flip_h(self) -> "Sample":  # types.rs:115-122
-        return Sample(flip_h_bits(self.mask), flip_h_bits(self.value), self.policy[::-1].copy(), self.q_penalty, self.q_no_penalty)
+        s = Sample.__new__(Sample)
+        s.mask, s.value, s.policy = flip_h_bits(self.mask), flip_h_bits(self.value), self.policy[::-1].copy()
+        s.q_penalty, s.q_no_penalty = self.q_penalty, self.q_no_penalty
+        return s
 
     def to_numpy(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:  # types.rs:125-147
-        bits = np.arange(42, dtype=np.uint64)
-        p0 = ((np.uint64(self.value) >> bits) & np.uint64(1)).astype(np.float32)
-        p1 = ((np.uint64(self.mask & ~self.value) >> bits) & np.uint64(1)).astype(np.float32)
-        pos = np.concatenate([p0, p1]).reshape(2, N_ROWS, N_COLS)  # c4r.rs:378-392
+        # c4r.rs:378-392: plane 0 = the bits of `value` (the side to move), plane 1 = the bits of `mask & !value`, bit = row * 7 + col
+        planes = np.unpackbits(np.array([self.value, self.mask & ~self.value], dtype="<u8").view(np.uint8), bitorder="little")
+        pos = planes.reshape(2, 64)[:, :42].astype(np.float32).reshape(2, N_ROWS, N_COLS)
         return pos, self.policy.copy(), np.array(self.q_penalty, dtype=np.float32), np.array(self.q_no_penalty, dtype=np.float32)
 
     def pos_str(self) -> str:  # types.rs:150-152 / c4r.rs:395-413

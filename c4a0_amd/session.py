@@ -308,15 +308,21 @@ class DeviceSession:
         return self.rows != before
 
     def run(self, evaluator: DeviceEvaluator, max_steps: Optional[int] = None, poll_every: int = 16,
-            on_step: Optional[Callable[[int], None]] = None, steps_per_graph: int = 0) -> int:
+            on_step: Optional[Callable[[int], None]] = None, steps_per_graph: int = 0, phases: Optional[dict] = None) -> int:
         """Play all games set by set_games() to completion.  Returns the number of steps.
 
         steps_per_graph > 0 replays a HIP graph of that many (evaluator, step) rounds per host
-        iteration -- for evaluators that are pure device code (no host callbacks)."""
+        iteration -- for evaluators that are pure device code (no host callbacks).  phases (a dict) receives where the wall
+        time went, as session._run_pair fills it."""
+        import time
+
         self.bind()
         self.start()
         steps = 0
+        t_c = time.perf_counter()
         graph = self.capture_steps(evaluator, steps_per_graph) if steps_per_graph > 0 else None
+        if phases is not None:
+            phases.update(first_capture_s=time.perf_counter() - t_c, recapture_s=0.0, captures=1 if graph is not None else 0, t_loop0=time.perf_counter())
         # The host enqueues much faster than the GPU executes.  Unthrottled it would run thousands of
         # steps ahead of the completion probe and the job would keep evaluating idle slots long after
         # the last game ended, so at most `max_chunks_in_flight` chunks (a graph replay, or
@@ -344,16 +350,23 @@ class DeviceSession:
                 inflight.append(ev)
                 if len(inflight) > max_chunks_in_flight:
                     inflight.pop(0).synchronize()
-                done, err = self.poll()
+                done, started, err = self.progress()
                 if err:
                     self.raise_if_device_error()
+                if phases is not None and started >= self.n_games and "t_all_started" not in phases:
+                    phases["t_all_started"], phases["steps_all_started"] = time.perf_counter(), steps   # as the (slightly late) probe sees it
                 if done >= self.n_games:
                     break
                 chunks += 1
                 if graph is not None and chunks % max(1, self.NARROW_CHECK_ROUNDS // steps_per_graph) == 0 and \
                         self.narrow_if_worthwhile(asynchronous=bool(getattr(evaluator, "batch_invariant", False))):
                     inflight.clear()
+                    t_c = time.perf_counter()
                     graph = self.capture_steps(evaluator, steps_per_graph)   # the old graph carries the old width
+                    if phases is not None:
+                        phases["recapture_s"] += time.perf_counter() - t_c
+                        phases["captures"] += 1
+                        phases.setdefault("narrowings", []).append((steps, [self.rows]))
             if max_steps is not None and steps >= max_steps:
                 break
         if graph is not None:

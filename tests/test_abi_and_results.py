@@ -471,3 +471,29 @@ def test_gemm_block_to_tile_map_is_a_bijection_for_every_grid():
     # more tiles along m than the packed 16-bit kernel argument holds: refused, not wrapped
     nb = C.c_uint32(0)
     assert L.c4_linear_bf16_tile_map(64 * 70001, 192, 64, 64, None, 0, C.byref(nb)) != 0
+
+
+def test_request_table_and_resident_games_defaults():
+    """Host logic of play_games that needs no GPU: the request list is read in ONE pass into a uint64[n, 3] table (bad objects ->
+    TypeError as extract() fails in the reference, pybridge.rs:30; ids outside u64 -> OverflowError as PyO3's), and the number of
+    resident games when the caller does not say: everything up to 4 096 games, then the largest of 4 096 / 8 192 / 16 384 that the
+    job fills four times over (profiles/r06_whole_call.txt), 4 096 for host-callback modes."""
+    from c4a0_amd import GameMetadata
+    from c4a0_amd.api import _ids_of, _validate, default_resident_games
+
+    ids = _ids_of([GameMetadata(5, 1, 2), GameMetadata((1 << 64) - 1, 0, 0)])
+    assert ids.dtype == np.uint64 and ids.tolist() == [[5, 1, 2], [(1 << 64) - 1, 0, 0]]
+    assert _ids_of([]).shape == (0, 3)
+    with pytest.raises(TypeError):
+        _ids_of([(1, 2, 3)])
+    class Bad:
+        game_id, player0_id, player1_id = -1, 0, 0
+    with pytest.raises(OverflowError):
+        _ids_of([Bad()])
+    with pytest.raises(TypeError):      # two different players need one evaluator per model
+        _validate([GameMetadata(0, 1, 2)], 8, 10, None, lambda x: x)
+    with pytest.raises(KeyError):
+        _validate([GameMetadata(0, 1, 2)], 8, 10, None, {1: None})
+    got = {n: default_resident_games(n, 100, True) for n in (1, 100, 4096, 4097, 16384, 32767, 32768, 40960, 65535, 65536, 10 ** 6)}
+    assert got == {1: 1, 100: 100, 4096: 4096, 4097: 4096, 16384: 4096, 32767: 4096, 32768: 8192, 40960: 8192, 65535: 8192, 65536: 16384, 10 ** 6: 16384}
+    assert default_resident_games(10 ** 6, 100, False) == 4096
