@@ -14,6 +14,7 @@ The tree path always runs in the HIP kernels; there is no CPU implementation to 
 """
 from __future__ import annotations
 
+import time
 from typing import Callable, Optional, Sequence
 
 import numpy as np
@@ -314,7 +315,6 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
         steps_per_graph = tail_steps_per_graph = 32 if (len(reqs) >= 32 * n_slots or int(n_mcts_iterations) >= 400) else 8
     if hasattr(evaluator, "latency_mode"):   # InferenceNet: tile choice of the narrow layers, alone vs beside another session
         evaluator.latency_mode = parts == 1
-    import time
     phases = {} if stats is not None else None
     t_play0 = time.perf_counter()
     sessions = []

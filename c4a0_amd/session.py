@@ -9,6 +9,7 @@ PyTorch supplies device memory and streams only.
 from __future__ import annotations
 
 import ctypes as C
+import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -25,6 +26,33 @@ DeviceEvaluator = Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]
 # its events with hipEventQuery for as long as a process group lives -- invalidates it, and a training loop calls
 # play_games_sharded with the group up and collectives just issued (tests/test_gpu_sharded.py).
 CAPTURE_ERROR_MODE = "thread_local"
+
+
+class _capture:
+    """`torch.cuda.graph(graph, stream=..., capture_error_mode=...)` without its `torch.cuda.empty_cache()`: a job re-captures its
+    graph at every narrowing of its tail (5-7 captures per job), and handing every cached block back to the driver before each one
+    -- and allocating the capture's activations afresh -- is most of what a capture costs (profiles/r06_whole_call.txt (e)).
+    The callers synchronise the device themselves before they capture."""
+
+    def __init__(self, graph: "torch.cuda.CUDAGraph", stream: Optional[torch.cuda.Stream] = None):
+        self.graph = graph
+        self.stream = stream if stream is not None else torch.cuda.Stream()   # a capture cannot run on the legacy default stream
+        self.ctx = torch.cuda.stream(self.stream)
+
+    def __enter__(self):
+        self.ctx.__enter__()
+        self.graph.capture_begin(capture_error_mode=CAPTURE_ERROR_MODE)
+
+    def __exit__(self, *args):
+        self.graph.capture_end()
+        self.ctx.__exit__(*args)
+
+
+def capture(graph: "torch.cuda.CUDAGraph", stream: Optional[torch.cuda.Stream] = None):
+    return _capture(graph, stream) if LEAN_CAPTURE else torch.cuda.graph(graph, stream=stream, capture_error_mode=CAPTURE_ERROR_MODE)
+
+
+LEAN_CAPTURE = True   # (False: torch.cuda.graph's own entry, the A/B)
 
 
 class DeviceSession:
@@ -184,7 +212,7 @@ class DeviceSession:
         main.wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream, capture_error_mode=CAPTURE_ERROR_MODE):
+        with capture(graph, stream if stream is not None else torch.cuda.Stream(device=self.device)):   # (never the legacy default stream)
             self.bind(torch.cuda.current_stream(self.device))
             for _ in range(steps_per_graph):
                 self.round(evaluator)
@@ -314,8 +342,6 @@ class DeviceSession:
         steps_per_graph > 0 replays a HIP graph of that many (evaluator, step) rounds per host
         iteration -- for evaluators that are pure device code (no host callbacks).  phases (a dict) receives where the wall
         time went, as session._run_pair fills it."""
-        import time
-
         self.bind()
         self.start()
         steps = 0
@@ -422,7 +448,7 @@ def capture_pair(sessions: Sequence["DeviceSession"], streams: Sequence[torch.cu
     graph = torch.cuda.CUDAGraph()
     prev_hook = getattr(evaluator, "stage_hook", None)
     try:
-        with torch.cuda.graph(graph, stream=s0, capture_error_mode=CAPTURE_ERROR_MODE):
+        with capture(graph, s0):
             a.bind(s0)
             b.bind(s1)
             s1.wait_stream(s0)                                  # fork: s1 joins the capture
@@ -537,8 +563,6 @@ def _run_pair(sessions, streams, evaluator, steps_per_graph, max_chunks_in_fligh
     steps_per_graph rounds per replay while slots are refilled (long graphs amortise the replay boundary: at BASELINE
     config 2, 8 -> 0.109 ms per round, 64 -> 0.104); from the first narrowing on -- the graph has to be captured again there
     anyway -- tail_steps_per_graph rounds (default: the same), so that the job's end is noticed within a few short replays."""
-    import time
-
     dev = sessions[0].device
     t_c = time.perf_counter()
     graph = capture_pair(sessions, streams, evaluator, steps_per_graph)

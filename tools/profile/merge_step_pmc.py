@@ -38,6 +38,10 @@ out["derived_65536"] = {
     "wavefronts_per_simd": waves_per_simd,
     "issue_slots_taken": round(pw["SQ_ACTIVE_INST_ANY_per_wave"] * waves_per_simd / pw["SQ_WAVE_CYCLES_per_wave"], 3),
     "valu_share_of_issue_cycles": round(pw["SQ_ACTIVE_INST_VALU_per_wave"] / pw["SQ_ACTIVE_INST_ANY_per_wave"], 3),
-    "reading": "a wavefront issues for issue_cycles of its lifetime; four wavefronts share a SIMD (127-128 VGPRs), so issue_slots_taken of the SIMD's issue cycles are "
-               "in use: the kernel is bound by instruction issue (VALU above all), not by bytes"}
+    "valu_pipe_busy": round(pw["SQ_ACTIVE_INST_VALU_per_wave"] * waves_per_simd / pw["SQ_WAVE_CYCLES_per_wave"], 3),
+    "scalar_pipe_busy": round(pw["SQ_ACTIVE_INST_SCA_per_wave"] * waves_per_simd / pw["SQ_WAVE_CYCLES_per_wave"], 3),
+    "reading": "a wavefront issues for issue_cycles of its lifetime; four wavefronts share a SIMD (127-128 VGPRs), so issue_slots_taken of the SIMD's cycles have "
+               "some wavefront of it issuing -- an upper bound on how full the issue stage is, because instructions of DIFFERENT types from different wavefronts can "
+               "issue in the same cycle; the vector ALU alone is busy valu_pipe_busy of the time (a wave64 VALU instruction occupies the SIMD for one quad-cycle).  Either "
+               "way the kernel is bound by instruction issue and the dependent-load latency four wavefronts cannot hide, not by bytes"}
 print(json.dumps(out, indent=1))

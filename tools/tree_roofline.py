@@ -14,6 +14,7 @@ import json
 import os
 import sys
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,7 +36,9 @@ def main():
     for g in [int(x) for x in args.games.split(",")]:
         s = DeviceSession(g, args.n_mcts, 6.6, 0.01, device=dev, planes_dtype=torch.bfloat16, blocks_per_slot=args.blocks_per_slot)
         n_games = g * 8
-        s.set_games([(i, 0, 0) for i in range(n_games)])
+        ids = np.zeros((n_games, 3), dtype=np.uint64)
+        ids[:, 0] = np.arange(n_games, dtype=np.uint64)
+        s.set_games(ids)
         s.bind()
         s.start()
         s.logprobs.fill_(1.0 / 7.0)
