@@ -898,12 +898,12 @@ def main():
                 if "gemm_pooled" in rocprof and "gemm_first_hidden" in kernels and "gemm_narrow" in kernels:
                     g1, g2 = kernels["gemm_first_hidden"], kernels["gemm_narrow"]
                     n_l = g1["launches_measured"] + g2["launches_measured"]
-                    fl = (g1["flops_per_launch"] * g1["launches_measured"] + g2["flops_per_launch"] * g2["launches_measured"]) / n_l
+                    fl_pooled = (g1["flops_per_launch"] * g1["launches_measured"] + g2["flops_per_launch"] * g2["launches_measured"]) / n_l
                     us = (g1["avg_us"] * g1["launches_measured"] + g2["avg_us"] * g2["launches_measured"]) / n_l
                     kernels["gemm_pooled"] = {"kernel": "c4_head_gemm_kernel, all three hidden-layer launches of a round pooled (as rocprofv3 names them: one instance)",
-                                              "calls_per_round": n_l / tl_rounds, "avg_us": us, "rocprof_avg_us": rocprof["gemm_pooled"], "flops_per_launch": fl,
-                                              "frac_of_mfma_peak": fl / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                                              "rocprof_frac_of_mfma_peak": fl / (rocprof["gemm_pooled"] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+                                              "calls_per_round": n_l / tl_rounds, "avg_us": us, "rocprof_avg_us": rocprof["gemm_pooled"], "flops_per_launch": fl_pooled,
+                                              "frac_of_mfma_peak": fl_pooled / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                              "rocprof_frac_of_mfma_peak": fl_pooled / (rocprof["gemm_pooled"] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
                 if "tower" in kernels and "rocprof_avg_us" in kernels["tower"]:
                     kernels["tower"]["rocprof_frac_of_mfma_peak"] = kernels["tower"]["flops_per_launch"] / (kernels["tower"]["rocprof_avg_us"] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS
                 if fused and "rocprof_avg_us" in fused:

@@ -1046,6 +1046,36 @@ int c4o_eval_hash(void* ctx, uint64_t model_id, int n, const float* planes, floa
   return 0;
 }
 
+/* Table evaluator (parity tier T3 at full size): answers a position with what ANOTHER evaluator said for it -- the rows
+ * (mask, value) -> (7 log-probabilities, q_penalty, q_no_penalty) a device run logged, sorted by (mask, value), binary search.
+ * A position the table does not hold must be a terminal one (the device never shows its evaluator a terminal leaf it can
+ * resolve in the launch that selected it; the reference asks and ignores the answer, mcts.rs:92-98): zeros.  Anything else is
+ * a divergence between the two searches: error 1 (c4o_self_play fails).  Not part of the reference; a test fake. */
+int c4o_eval_table(void* ctx, uint64_t model_id, int n, const float* planes, float* lp, float* qp, float* qn) {
+  (void)model_id;
+  const c4o_eval_table_ctx* t = (const c4o_eval_table_ctx*)ctx;
+  for (int i = 0; i < n; i++) {
+    c4o_pos p;
+    planes_to_pos(planes + (size_t)84 * i, &p);
+    uint64_t lo = 0, hi = t->n;
+    while (lo < hi) {
+      const uint64_t mid = lo + (hi - lo) / 2;
+      if (t->mask[mid] < p.mask || (t->mask[mid] == p.mask && t->value[mid] < p.value)) lo = mid + 1; else hi = mid;
+    }
+    if (lo < t->n && t->mask[lo] == p.mask && t->value[lo] == p.value) {
+      memcpy(lp + 7 * i, t->out + 9 * lo, 7 * sizeof(float));
+      qp[i] = t->out[9 * lo + 7];
+      qn[i] = t->out[9 * lo + 8];
+    } else if (c4o_terminal_state(&p) != C4O_NOT_TERMINAL) {
+      memset(lp + 7 * i, 0, 7 * sizeof(float));
+      qp[i] = qn[i] = 0.0f;
+    } else {
+      return 1;
+    }
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * self_play -- rust/src/self_play.rs:39-129.  The reference runs one NNThread (196-237) and
  * ncpu-1 MctsThreads (268-323) exchanging games over channels; which games share an NN batch

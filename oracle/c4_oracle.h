@@ -192,6 +192,9 @@ int c4o_self_play_async(const c4o_game_metadata* reqs, uint64_t n_games, int max
  * workers one per CPU over the rest, for the duration of each c4o_self_play_async call.  No effect on results. */
 void c4o_set_thread_pinning(int on);
 
+/* c4o_eval_table's ctx: n rows sorted by (mask, value); out[9 * i ..] = 7 log-probabilities, q_penalty, q_no_penalty */
+typedef struct { uint64_t n; const uint64_t* mask; const uint64_t* value; const float* out; } c4o_eval_table_ctx;
+int c4o_eval_table(void* ctx, uint64_t model_id, int n, const float* planes, float* lp, float* qp, float* qn);
 /* built-in evaluators usable as c4o_eval_fn (ctx ignored) */
 int c4o_eval_uniform(void* ctx, uint64_t model_id, int n, const float* planes,
                      float* logprobs, float* q_pen, float* q_nopen); /* self_play.rs:391-403: logits=1/7, q=0 */

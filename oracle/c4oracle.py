@@ -74,6 +74,10 @@ class SelfPlayStats(C.Structure):
                 ("nn_positions", C.c_uint64), ("tree", Counters)]
 
 
+class EvalTableCtx(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("mask", C.c_void_p), ("value", C.c_void_p), ("out", C.c_void_p)]
+
+
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_float),
                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float))
 
@@ -440,11 +444,20 @@ def self_play(reqs: Sequence[Tuple[int, int, int]], max_nn_batch_size: int, n_mc
     offs = (C.c_uint64 * (n + 1))()
     stats = SelfPlayStats()
     keep = None
+    err: List[BaseException] = []
+    ctx = None
     if isinstance(evaluator, str):
         fn = C.cast(getattr(L, {"uniform": "c4o_eval_uniform", "zeros": "c4o_eval_zeros", "hash": "c4o_eval_hash"}[evaluator]), C.c_void_p)
+    elif isinstance(evaluator, tuple) and evaluator[0] == "table":
+        # ("table", mask uint64[n], value uint64[n], out float32[n, 9]) sorted by (mask, value): c4o_eval_table, tier T3 at full size
+        _tag, t_mask, t_value, t_out = evaluator
+        t_mask, t_value = np.ascontiguousarray(t_mask, dtype=np.uint64), np.ascontiguousarray(t_value, dtype=np.uint64)
+        t_out = np.ascontiguousarray(t_out, dtype=np.float32).reshape(-1, 9)
+        assert len(t_mask) == len(t_value) == len(t_out)
+        keep = (t_mask, t_value, t_out, EvalTableCtx(len(t_mask), t_mask.ctypes.data, t_value.ctypes.data, t_out.ctypes.data))
+        ctx = C.cast(C.pointer(keep[3]), C.c_void_p)
+        fn = C.cast(L.c4o_eval_table, C.c_void_p)
     else:
-        err: List[BaseException] = []
-
         def _cb(_ctx, model_id, nb, planes_p, lp_p, qp_p, qn_p):
             try:
                 x = np.ctypeslib.as_array(planes_p, shape=(nb, 2, 6, 7)).copy()
@@ -467,9 +480,9 @@ def self_play(reqs: Sequence[Tuple[int, int, int]], max_nn_batch_size: int, n_mc
         raise ValueError("topology must be 'lockstep' or 'async'")
     entry = L.c4o_self_play_async if topology == "async" else L.c4o_self_play
     rc = entry(arr, n, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty,
-               fn, None, n_threads, out, offs, C.byref(stats))
+               fn, ctx, n_threads, out, offs, C.byref(stats))
     L.c4o_self_play_set_dirichlet(0.0, 0.0)
-    if keep is not None and err:
+    if err:
         raise err[0]
     if rc:
         raise RuntimeError(f"oracle self_play error {rc}")

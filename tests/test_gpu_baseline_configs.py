@@ -8,6 +8,8 @@ and replays a subset of the games in the oracle, bit for bit:
   * bf16 network: T3 replay -- the run logs every (leaf -> evaluator output) pair the
     subset's slots consumed, the oracle replays those games with a lookup evaluator.
 Reference: rust/src/self_play.rs:268-323, mcts.rs:83-108."""
+import os
+
 import numpy as np
 import pytest
 
@@ -100,6 +102,84 @@ def _oracle_replay(seq_by_slot, slot_ids, n_iter, dirichlet=(0.0, 0.0)):
     return out
 
 
+_COL0 = 0x810204081
+_COL_UP_TO = np.array([_COL0 & ((1 << (7 * h)) - 1) for h in range(8)], dtype=np.uint64)   # column 0's cells below height h
+
+
+def _keys_to_positions(keys):
+    """c4_session_leaf_keys' int64 (value bits | 7 column heights << 42) -> (mask, value) uint64 arrays."""
+    k = keys.astype(np.uint64)
+    value = k & np.uint64((1 << 42) - 1)
+    mask = np.zeros_like(value)
+    for c in range(7):
+        h = (k >> np.uint64(42 + 3 * c)) & np.uint64(7)
+        mask |= _COL_UP_TO[h.astype(np.int64)] << np.uint64(c)
+    return mask, value
+
+
+def _run_logging_every_row(net, ids, n_slots, n_iter):
+    """One eager session; at EVERY step the key of every slot's leaf and the evaluator's answer for it are logged on the device.
+    Returns (records, counts, counters, table) with table = (mask, value, out[n, 9]) sorted by (mask, value): what the evaluator
+    said for every distinct position it was shown during the whole job -- after checking that it said the SAME bits every time it
+    was shown a position again (the evaluator is a function of the position), over every row of every step."""
+    import ctypes as C
+    from c4a0_amd._lib import check
+    from c4a0_amd.session import DeviceSession
+
+    dev = torch.device("cuda:0")
+    s = DeviceSession(n_slots, n_iter, 6.6, 0.01, device=dev, planes_dtype=torch.bfloat16)
+    s.set_games([(g, 0, 0) for g in ids])
+    log_k, log_o = [], []
+
+    def log(_step):
+        keys = torch.empty(n_slots, dtype=torch.int64, device=dev)
+        check(s.L.c4_session_leaf_keys(s._h, C.c_void_p(keys.data_ptr())))
+        log_k.append(keys)
+        log_o.append(torch.cat([s.logprobs, s.q], dim=1))      # [n_slots, 9], a copy
+
+    s.run(net, on_step=log, poll_every=64)
+    recs, counts, ctr = s.drain_samples(), s.sample_counts(), s.counters()
+    s.close()
+    keys = torch.stack(log_k).reshape(-1)
+    out = torch.stack(log_o).reshape(-1, 9)
+    live = keys >= 0
+    keys, out = keys[live], out[live]
+    order = torch.argsort(keys, stable=True)
+    keys, out = keys[order], out[order]
+    dup = keys[1:] == keys[:-1]
+    same_bits = (out.view(torch.int32)[1:][dup] == out.view(torch.int32)[:-1][dup]).all()
+    assert bool(same_bits), "the evaluator answered one position with different bits in different rows / steps"
+    first = torch.ones_like(keys, dtype=torch.bool)
+    first[1:] = ~dup
+    n_rows, n_dup = int(keys.numel()), int(dup.sum())
+    keys_u, out_u = keys[first].cpu().numpy(), out[first].cpu().numpy()
+    mask, value = _keys_to_positions(keys_u)
+    o = np.lexsort((value, mask))
+    return recs, counts, ctr, (mask[o], value[o], np.ascontiguousarray(out_u[o])), (n_rows, n_dup)
+
+
+def test_config2_every_game_of_a_generation_replayed_by_the_oracle_with_the_networks_own_answers():
+    """T3 at FULL size (round 6; subsets of 24-96 games before): BASELINE config 2's 4 096 games with the real bf16
+    4 x 32 network, one generation.  The run logs what the evaluator answered for every row of every step (6 M rows); those
+    answers, keyed by position, become the oracle's evaluator (c4o_eval_table: a position it was never shown and that is not
+    terminal fails the replay), and EVERY game's samples must equal the oracle's bit for bit.  On the way: every position the
+    evaluator saw more than once got the same bits every time."""
+    from oracle import c4oracle as O
+    from tests.helpers import evidence, oracle_samples_by_game, samples_by_game
+    from tests.test_gpu_full_size import _check_structure
+
+    n, n_iter = 4096, 100
+    ids = list(range(n))
+    recs, counts, ctr, table, (n_rows, n_dup) = _run_logging_every_row(_net(4, 32), ids, n, n_iter)
+    assert ctr["games_done"] == n and ctr["error"] == 0
+    _check_structure(recs, counts, ids)
+    want, ost = O.self_play([(g, 0, 0) for g in ids], 4096, n_iter, 6.6, 0.01, ("table",) + table,
+                            n_threads=max(2, min(16, os.cpu_count() or 2)), topology="async")
+    assert samples_by_game(recs) == oracle_samples_by_game(want)
+    evidence(f"config 2 with the bf16 4x32 network (4 096 games, n = 100): ALL {n} games replayed by the oracle from the evaluator's own answers (T3): "
+             f"{len(recs)} samples identical; {n_rows} evaluator rows logged, {n_dup} of them repeats of a position, every repeat answered with the same bits")
+
+
 def _subset(recs, sub):
     from tests.helpers import samples_by_game
 
@@ -132,8 +212,8 @@ def test_config4_4096_games_n800_hash_evaluator_structure_and_oracle_subset():
     assert ctr["games_done"] == n and ctr["error"] == 0 and ctr["samples"] == len(recs) == counts.sum()
     _check_structure(recs, counts, ids)
     assert ctr["sims"] / n > 7 * 300
-    sub = sorted(np.random.default_rng(4).choice(ids, 128, replace=False).tolist())   # round 5: 128 games through the oracle (16 before)
-    want, _ = O.self_play([(g, 0, 0) for g in sub], 64, n_iter, 6.6, 0.01, "hash", n_threads=8)
+    sub = sorted(np.random.default_rng(4).choice(ids, 1024, replace=False).tolist())   # round 6: 1 024 games through the oracle (128 in round 5, 16 before): 10 M simulations
+    want, _ = O.self_play([(g, 0, 0) for g in sub], 4096, n_iter, 6.6, 0.01, "hash", n_threads=max(2, min(16, os.cpu_count() or 2)), topology="async")
     assert _subset(recs, sub) == oracle_samples_by_game(want)
     from tests.helpers import evidence
     evidence(f"config 4 tree shape (4 096 games, n = 800, hash evaluator): {len(recs)} samples structurally checked, {len(sub)} games == oracle bit for bit")

@@ -1,7 +1,10 @@
-"""GPU tests at BASELINE.json's full sizes through size-independent properties of the domain
-(the oracle is too slow to replay 4 096 x 1 500 sims in the suite's budget, so a random subset of
-games is compared bit for bit and every game is checked structurally), plus the reference's
-default search width n_mcts_iterations = 1400 (src/c4a0/main.py:41)."""
+"""GPU tests at BASELINE.json's full sizes: size-independent properties of the domain (every game is
+checked structurally; the same bytes whatever the placement) AND, since round 6, every one of config 2's
+4 096 games against the oracle bit for bit (the C oracle in the reference's thread topology plays the
+6 M simulations in a few seconds), plus the reference's default search width n_mcts_iterations = 1400
+(src/c4a0/main.py:41)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -73,14 +76,14 @@ def test_config2_size_properties_placement_independence_and_oracle_subset():
     assert recs2.tobytes() == recs.tobytes() and np.array_equal(counts, counts2)
     assert {k: ctr[k] for k in ("sims", "select_levels", "backup_nodes", "expansions", "moves")} == \
            {k: ctr2[k] for k in ("sims", "select_levels", "backup_nodes", "expansions", "moves")}
-    # a random subset replayed by the oracle, bit for bit
-    rng = np.random.default_rng(1)
-    sub = sorted(rng.choice(n, 128, replace=False).tolist())          # round 6: 128 games through the oracle (48 before), 8 oracle threads
-    want, _ = O.self_play([(g, 0, 0) for g in sub], 64, 100, 6.6, 0.01, "hash", n_threads=8)
-    got = samples_by_game(recs[np.isin(recs["game_id"], np.array(sub, dtype=np.uint64))])
+    # EVERY game replayed by the oracle, bit for bit (round 6: all 4 096; 128 in round 5's run, 48 before -- the C oracle in the
+    # reference's thread topology plays config 2's 6 M simulations in a few seconds on the GPU box's host cores)
+    sub = ids
+    want, _ = O.self_play([(g, 0, 0) for g in sub], 4096, 100, 6.6, 0.01, "hash", n_threads=max(2, min(16, os.cpu_count() or 2)), topology="async")
+    got = samples_by_game(recs)
     assert got == oracle_samples_by_game(want)
     from tests.helpers import evidence
-    evidence(f"config 2 (4 096 games, n = 100, hash evaluator): {len(recs)} samples structurally checked, 2 placements byte-identical, {len(sub)} games == oracle bit for bit")
+    evidence(f"config 2 (4 096 games, n = 100, hash evaluator): {len(recs)} samples structurally checked, 2 placements byte-identical, ALL {len(sub)} games == oracle bit for bit")
     # every game needs at least 7 moves x (n - retained) sims
     assert ctr["sims"] / n > 300 and 8 <= len(recs) / n <= 43
 

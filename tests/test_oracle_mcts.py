@@ -284,3 +284,32 @@ def test_async_topology_gives_the_samples_of_the_lockstep_restatement():
         raise RuntimeError("evaluator failure")
     with pytest.raises(RuntimeError):
         O.self_play(reqs[:8], 64, 9, 6.6, 0.01, failing, n_threads=3, topology="async")
+
+
+def test_table_evaluator_replays_a_run_from_its_logged_answers():
+    """c4o_eval_table (tier T3 at full size, tests/test_gpu_baseline_configs.py): an evaluator that answers a position with what another
+    evaluator said for it.  A run through a callback that logs (position -> answer) and the replay from the sorted table give the same
+    samples on 1 and 4 threads; a table that lacks non-terminal positions fails the replay instead of inventing an answer."""
+    from tests.helpers import hash_eval_np, oracle_samples_by_game, planes_to_pos_np
+
+    reqs = [(g, 0, 0) for g in range(24)]
+    seen = {}
+
+    def cb(model_id, x):
+        lp, qp, qn = hash_eval_np(model_id, x)
+        m, v = planes_to_pos_np(x)
+        for i in range(len(m)):
+            seen[(int(m[i]), int(v[i]))] = np.concatenate([lp[i], [qp[i]], [qn[i]]]).astype(np.float32)
+        return lp, qp, qn
+
+    want, _ = O.self_play(reqs, 64, 25, 6.6, 0.01, cb)
+    keys = sorted(k for k in seen if O.terminal_state(O.Pos(*k)) == 0)          # terminal leaves: asked, never used (mcts.rs:92-98)
+    assert len(keys) < len(seen)
+    mask = np.array([k[0] for k in keys], dtype=np.uint64)
+    value = np.array([k[1] for k in keys], dtype=np.uint64)
+    out = np.stack([seen[k] for k in keys])
+    for threads, topology in ((1, "lockstep"), (4, "async")):
+        got, _ = O.self_play(reqs, 64, 25, 6.6, 0.01, ("table", mask, value, out), n_threads=threads, topology=topology)
+        assert oracle_samples_by_game(got) == oracle_samples_by_game(want)
+    with pytest.raises(RuntimeError):
+        O.self_play(reqs, 64, 25, 6.6, 0.01, ("table", mask[:-7], value[:-7], out[:-7]))
