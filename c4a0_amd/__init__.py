@@ -14,6 +14,9 @@ def __getattr__(name):  # torch / the HIP library are loaded on first use of the
     if name in ("play_games", "run_tui", "DeviceCallback", "trim_cached_memory"):
         from . import api
         return getattr(api, name)
+    if name == "play_games_native":
+        from .native import play_games_native
+        return play_games_native
     if name == "play_games_sharded":
         from .distributed import play_games_sharded
         return play_games_sharded

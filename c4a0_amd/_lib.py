@@ -21,7 +21,7 @@ FLAG_ONE_SIM_PER_STEP = 2
 FLAG_RECLAIM = 4          # include/c4a0_hip.h C4_FLAG_RECLAIM: the tree arena is reclaimed while a game is played
 FLAG_NO_RECLAIM = 8       # ... never, also where the default sizing would
 MAX_SAMPLES_PER_GAME = 43
-ABI_VERSION = 8   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
+ABI_VERSION = 9   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
 STRUCT_LAYOUT_SINCE = 7   # the ABI version that last changed a structure's layout (c4_config.reclaim_period, c4_counters.reclaim_*)
 
 
@@ -54,6 +54,31 @@ class Counters(C.Structure):
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class NetworkBf16(C.Structure):
+    """include/c4a0_hip.h c4_network_bf16."""
+    _fields_ = [("channels", C.c_uint32), ("n_blocks", C.c_uint32), ("tower_w0", C.c_void_p), ("tower_w", C.c_void_p), ("tower_bias", C.c_void_p),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("n_policy_hidden", C.c_uint32), ("n_value_hidden", C.c_uint32),
+                ("policy_w", C.c_void_p * 8), ("policy_b", C.c_void_p * 8), ("value_w", C.c_void_p * 8), ("value_b", C.c_void_p * 8),
+                ("policy_out_w", C.c_void_p), ("value_out_w", C.c_void_p), ("policy_out_b", C.c_void_p), ("value_out_b", C.c_void_p)]
+
+
+class PlayOptions(C.Structure):
+    """include/c4a0_hip.h c4_play_options."""
+    _fields_ = [("device", C.c_int32), ("resident_games", C.c_uint32), ("concurrent_sessions", C.c_uint32), ("steps_per_graph", C.c_uint32),
+                ("tail_steps_per_graph", C.c_uint32), ("blocks_per_slot", C.c_uint32), ("flags", C.c_uint32), ("reclaim_period", C.c_uint32),
+                ("dirichlet_alpha", C.c_float), ("dirichlet_epsilon", C.c_float), ("eval_cache_entries", C.c_uint64)]
+
+
+class PlayPhases(C.Structure):
+    """include/c4a0_hip.h c4_play_phases."""
+    _fields_ = [("setup_s", C.c_double), ("capture_s", C.c_double), ("steady_s", C.c_double), ("tail_s", C.c_double), ("drain_s", C.c_double),
+                ("rounds", C.c_uint64), ("rounds_until_all_started", C.c_uint64), ("graph_captures", C.c_uint32), ("resident_games", C.c_uint32),
+                ("sessions", C.c_uint32), ("rows_at_end", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 # every symbol include/c4a0_hip.h declares: name -> (restype, argtypes)
@@ -91,6 +116,8 @@ SIGNATURES = {
     "c4_trim_cached_memory": (C.c_int, []),
     "c4_records_to_cbor": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, _P(C.c_uint64)]),
     "c4_shuffle_games": (C.c_int, [C.c_uint64, C.c_uint64, _vp]),
+    "c4_play_games_bf16": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_float, C.c_float, _P(NetworkBf16), _P(PlayOptions), _vp, _vp, C.c_uint64,
+                                     _P(C.c_uint64), _P(Counters), _P(PlayPhases)]),
     "c4_cbor_to_records": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _vp, C.c_uint64, _P(C.c_uint64), _P(C.c_uint64)]),
     "c4_session_leaf_keys": (C.c_int, [_vp, _vp]),
     "c4_session_unique_leaves": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),

@@ -19,7 +19,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libc4a0_hip.so")
-SRCS = [os.path.join(HERE, "c4_session.hip"), os.path.join(HERE, "c4_conv_tower.hip"), os.path.join(HERE, "c4_head_gemm.hip"), os.path.join(HERE, "c4_results_host.hip")]
+SRCS = [os.path.join(HERE, "c4_session.hip"), os.path.join(HERE, "c4_conv_tower.hip"), os.path.join(HERE, "c4_head_gemm.hip"), os.path.join(HERE, "c4_results_host.hip"), os.path.join(HERE, "c4_selfplay_host.hip")]
 DEPS = SRCS + [os.path.join(HERE, "c4_device.hpp"), os.path.join(HERE, "c4_host.hpp"), os.path.join(HERE, "c4_head_out.hpp"), os.path.join(HERE, "c4_timeline.hpp"),
                os.path.join(os.path.dirname(PKG), "include", "c4a0_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -1,0 +1,86 @@
+"""`play_games` through the library's own host loop: `c4_play_games_bf16` (include/c4a0_hip.h, c4a0_amd/csrc/c4_selfplay_host.hip).
+
+The reference's `self_play()` (rust/src/self_play.rs:39-129) is compiled code that owns the whole loop; `c4_play_games_bf16` is
+that loop in the library -- sessions, streams, HIP-graph capture and replay, completion polling, tail narrowing, the merged
+hand-over of the records -- so that a Rust or C host plays a job with ONE call.  This module is the Python binding of the same
+call: it hands the library the device pointers of a `c4a0_amd.nn.InferenceNet` and returns a `PlayGamesResult`.  The Python loop of
+`c4a0_amd.api.play_games` / `c4a0_amd.session` implements the same schedule for every other kind of evaluator (numpy callbacks,
+arbitrary device callables, tournaments); with an `InferenceNet` the two return the same bytes (tests/test_gpu_native_host.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .results import PlayGamesResult, results_from_records
+
+
+def network_struct(net) -> _lib.NetworkBf16:
+    """c4_network_bf16 over the tensors of a c4a0_amd.nn.InferenceNet (which must stay alive while the struct is used)."""
+    import torch
+
+    if not (getattr(net, "path", None) == "hip" and net.dtype == torch.bfloat16 and net.merged_w1 is not None):
+        raise TypeError("the native host loop takes a bf16 c4a0_amd.nn.InferenceNet on the hand-written kernels whose heads both have a hidden layer")
+    s = _lib.NetworkBf16()
+    s.channels, s.n_blocks = net.channels, net.n_blocks
+    s.tower_w0, s.tower_w, s.tower_bias = net.tw0.data_ptr(), net.tw.data_ptr(), net.tbias.data_ptr()
+    s.w1, s.b1 = net.merged_w1.data_ptr(), net._bias32[net.merged_b1.data_ptr()].data_ptr()
+    pol = list(zip(net.pol_w[1:-1], net.pol_b[1:-1]))
+    val = list(zip(net.val_w[1:-1], net.val_b[1:-1]))
+    if len(pol) > 8 or len(val) > 8:
+        raise ValueError("at most 8 further hidden layers per head")
+    s.n_policy_hidden, s.n_value_hidden = len(pol), len(val)
+    for i, (w, b) in enumerate(pol):
+        s.policy_w[i], s.policy_b[i] = w.data_ptr(), net._bias32[b.data_ptr()].data_ptr()
+    for i, (w, b) in enumerate(val):
+        s.value_w[i], s.value_b[i] = w.data_ptr(), net._bias32[b.data_ptr()].data_ptr()
+    s.policy_out_w, s.value_out_w = net.pol_w[-1].data_ptr(), net.val_w[-1].data_ptr()
+    s.policy_out_b, s.value_out_b = net.pol_b32.data_ptr(), net.val_b32.data_ptr()
+    return s
+
+
+def play_games_native(reqs: Sequence, max_nn_batch_size: int, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float, net, *,
+                      resident_games: Optional[int] = None, concurrent_sessions: Optional[int] = None, steps_per_graph: int = 0,
+                      tail_steps_per_graph: int = 0, blocks_per_slot: int = 0, reclaim: Optional[bool] = None, reclaim_period: int = 0,
+                      dirichlet: Optional[tuple] = None, eval_cache_entries: int = 0, stats: Optional[dict] = None) -> PlayGamesResult:
+    """The reference's six arguments (max_nn_batch_size has no meaning in device mode: every resident game's leaf is a row) with
+    `net` in place of the callback, and `play_games`' keywords; the whole job runs inside ONE library call."""
+    from .api import _ids_of
+    from .session import SAMPLE_DTYPE
+
+    ids = _ids_of(reqs)
+    if bool((ids[:, 1] != ids[:, 2]).any()):
+        raise TypeError("games between different models need play_games(evaluator={model_id: evaluator, ...})")
+    if int(max_nn_batch_size) < 1 or int(n_mcts_iterations) < 0:
+        raise ValueError("max_nn_batch_size must be >= 1 and n_mcts_iterations >= 0")
+    n = len(ids)
+    if n == 0:
+        return PlayGamesResult([])
+    L = _lib.lib()
+    ns = network_struct(net)
+    opt = _lib.PlayOptions()
+    opt.device = net.device.index if net.device.index is not None else 0
+    opt.resident_games, opt.concurrent_sessions = int(resident_games or 0), int(concurrent_sessions or 0)
+    opt.steps_per_graph, opt.tail_steps_per_graph = int(steps_per_graph), int(tail_steps_per_graph)
+    opt.blocks_per_slot, opt.reclaim_period = int(blocks_per_slot), int(reclaim_period)
+    opt.flags = _lib.FLAG_RECLAIM if reclaim else (_lib.FLAG_NO_RECLAIM if reclaim is False else 0)
+    if dirichlet is not None:
+        opt.dirichlet_alpha, opt.dirichlet_epsilon = float(dirichlet[0]), float(dirichlet[1])
+    opt.eval_cache_entries = int(eval_cache_entries)
+    counts = np.empty(n, dtype=np.uint32)
+    recs = np.empty(n * _lib.MAX_SAMPLES_PER_GAME, dtype=SAMPLE_DTYPE)      # 43 per game always suffice; untouched pages are never made resident
+    n_recs, totals, phases = C.c_uint64(), _lib.Counters(), _lib.PlayPhases()
+    reqs_tab = np.ascontiguousarray(ids)
+    _lib.check(L.c4_play_games_bf16(reqs_tab.ctypes.data, n, int(n_mcts_iterations), float(c_exploration), float(c_ply_penalty), C.byref(ns),
+                                    C.byref(opt), counts.ctypes.data, recs.ctypes.data, len(recs), C.byref(n_recs), C.byref(totals), C.byref(phases)))
+    if stats is not None:
+        stats.update(totals.as_dict())
+        ph = phases.as_dict()
+        stats.update(steps=ph["rounds"], n_slots=ph["resident_games"], rows_at_end=ph["rows_at_end"], concurrent_sessions=ph["sessions"])
+        stats["phases"] = {"setup_s": ph["setup_s"], "start_and_capture_s": 0.0, "steady_s": ph["steady_s"], "tail_s": ph["tail_s"], "drain_s": ph["drain_s"],
+                           "graph_captures": ph["graph_captures"], "capture_s_inside_the_other_phases": ph["capture_s"],
+                           "rounds_until_all_started": ph["rounds_until_all_started"]}
+    return results_from_records(ids, recs[: n_recs.value], counts)

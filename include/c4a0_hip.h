@@ -24,10 +24,10 @@ extern "C" {
 #endif
 
 /* Version of THIS interface: bumped whenever a signature or a struct layout below changes (version 3 added `config` in the
- * middle of c4_conv_tower_bf16's arguments, version 5 c4_session_step_head_out, version 8 the host-side record codecs c4_records_to_cbor / c4_cbor_to_records / c4_shuffle_games).  A consumer compiled against this header checks it once at start-up --
+ * middle of c4_conv_tower_bf16's arguments, version 5 c4_session_step_head_out, version 8 the host-side record codecs c4_records_to_cbor / c4_cbor_to_records / c4_shuffle_games, version 9 c4_play_games_bf16).  A consumer compiled against this header checks it once at start-up --
  * `if (c4_abi_version() != C4_ABI_VERSION) refuse` -- because the dynamic linker compares names, not signatures
  * (tests/abi_consumer*.c and c4a0_amd/_lib.py do).  No reference counterpart: the reference's boundary is PyO3. */
-#define C4_ABI_VERSION 8
+#define C4_ABI_VERSION 9
 
 #define C4_N_COLS 7          /* rust/src/c4r.rs:45, lib.rs:28 */
 #define C4_N_ROWS 6          /* rust/src/c4r.rs:44, lib.rs:29 */
@@ -248,6 +248,78 @@ int c4_session_pack_samples(c4_session* s, c4_sample_rec* dst_dev, uint64_t cap,
 int c4_session_debug_phase_stamps(c4_session* s, uint64_t* out_host, uint64_t cap_words, uint64_t* n_words);
 /* Device views for collectives (RCCL all-gather of samples): records [n_games][43], counts [n_games]. */
 int c4_session_sample_store(c4_session* s, const c4_sample_rec** recs_dev, const uint32_t** counts_dev, uint64_t* n_games);
+
+/* ---- the body of self_play() as ONE call (rust/src/self_play.rs:39-129): for a host that keeps the folded bf16 network in device
+ * memory and does not want to write the schedule itself (c4a0_amd/csrc/c4_selfplay_host.hip says what the schedule is: two paired
+ * sessions in one HIP graph, the output layers inside the step's launch, long graphs while slots refill and short ones in the tail,
+ * narrowing, records merged in request order on the device).  Uses nothing but the entry points of this header and the HIP runtime.
+ *
+ * The network in the layouts the evaluator's entry points below take (what c4a0_amd/nn.py::InferenceNet holds: eval-mode BatchNorm
+ * folded, the tower's weights in MFMA fragment order -- pack_tower_weights --, the first Linear of each head with its input
+ * dimension permuted to the tower's [cell][channel] feature order): F = 42 * channels features; the first hidden layer of BOTH heads
+ * merged into one [2F][F] matrix (policy rows first), then n_policy_hidden / n_value_hidden further [F][F] hidden layers per head,
+ * then the output layers [7][F] and [2][F].  All weights bf16, all biases f32, all DEVICE pointers. */
+typedef struct {
+  uint32_t channels;          /* 32 or 64 (nn.py ModelConfig.conv_filter_size) */
+  uint32_t n_blocks;          /* residual blocks */
+  const void* tower_w0;       /* c4_conv_tower_bf16's w0_dev / w_dev / bias_dev */
+  const void* tower_w;
+  const float* tower_bias;
+  const void* w1;             /* merged first hidden layer [2F][F], b1 [2F] */
+  const float* b1;
+  uint32_t n_policy_hidden;   /* hidden layers of the policy head AFTER the merged one (nn.py n_policy_layers - 2), <= 8 */
+  uint32_t n_value_hidden;    /* ... of the value head (n_value_layers - 2), <= 8 */
+  const void* policy_w[8];
+  const float* policy_b[8];
+  const void* value_w[8];
+  const float* value_b[8];
+  const void* policy_out_w;   /* [7][F] */
+  const void* value_out_w;    /* [2][F] */
+  const float* policy_out_b;  /* [7] */
+  const float* value_out_b;   /* [2] */
+} c4_network_bf16;
+
+/* Everything optional (zero-initialise for the defaults; NULL = all defaults, device 0). */
+typedef struct {
+  int32_t device;                /* HIP device ordinal */
+  uint32_t resident_games;       /* games advanced in lock-step; 0 = by job size: 4 096 / 8 192 / 16 384 (c4a0_amd/api.py default_resident_games) */
+  uint32_t concurrent_sessions;  /* 0 = two paired sessions from 2 048 resident games, else one; 1 or 2 to force */
+  uint32_t steps_per_graph;      /* rounds per HIP-graph replay while slots are refilled; 0 = by job length (64 / 32 / 8) */
+  uint32_t tail_steps_per_graph; /* ... from the first narrowing of the tail on; 0 = 16 (8 for short jobs) */
+  uint32_t blocks_per_slot;      /* c4_config.blocks_per_slot */
+  uint32_t flags;                /* c4_config.flags (C4_FLAG_RECLAIM / C4_FLAG_NO_RECLAIM / C4_FLAG_ONE_SIM_PER_STEP) */
+  uint32_t reclaim_period;       /* c4_config.reclaim_period */
+  float dirichlet_alpha;         /* EXTENSION, off while epsilon == 0: c4_session_set_dirichlet */
+  float dirichlet_epsilon;
+  uint64_t eval_cache_entries;   /* EXTENSION, off at 0: c4_session_set_eval_cache (split over the sessions) */
+} c4_play_options;
+
+/* Where the call's wall time went (seconds) and what it chose. */
+typedef struct {
+  double setup_s;                /* sessions, arenas, activation buffers, streams */
+  double capture_s;              /* all graph captures (the first one and those after a narrowing: inside steady_s / tail_s too) */
+  double steady_s;               /* from the first replay until every request had been started (all slots busy) */
+  double tail_s;                 /* after that, until the last game ended */
+  double drain_s;                /* counters, merge, transfer of the records */
+  uint64_t rounds;               /* lock-step rounds replayed */
+  uint64_t rounds_until_all_started;
+  uint32_t graph_captures;
+  uint32_t resident_games;
+  uint32_t sessions;
+  uint32_t rows_at_end;          /* sum of the sessions' widths after the last narrowing */
+} c4_play_phases;
+
+/* Plays every game of reqs[0 .. n_games) to the end (self_play.rs:39-129 with the arguments of self_play.rs:39-46) and returns the
+ * samples in REQUEST order: counts_host[g] = samples of game g (<= 43), records_host = their records back to back (capacity
+ * records_cap records: 43 * n_games always suffice; a smaller buffer that turns out too small -> C4_ERR_BAD_ARG with the number
+ * needed in *n_records).  totals (may be NULL) = the sessions' counters summed; phases may be NULL.  Synchronous; the records are the
+ * same bytes whatever resident_games / concurrent_sessions / graph lengths are chosen (the evaluator is a function of the position,
+ * a game's samples do not depend on the slot or session that plays it).  A device-side error (C4_ERR_NAN_IN_TREE, ...) is returned
+ * as the status, with the slot in totals->error_slot. */
+int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games, uint32_t n_mcts_iterations, float c_exploration,
+                       float c_ply_penalty, const c4_network_bf16* net, const c4_play_options* options, uint32_t* counts_host,
+                       c4_sample_rec* records_host, uint64_t records_cap, uint64_t* n_records, c4_counters* totals,
+                       c4_play_phases* phases);
 
 /* ---- the hand-off right after the path: PlayGamesResult's wire format on the packed records (HOST functions: no device is
  * touched, they work on a machine without a GPU). ----

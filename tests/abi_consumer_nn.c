@@ -16,8 +16,10 @@
  *   P x (w [F][F] bf16, bias [F] f32) | V x (w, bias) | policy out w [7][F] bf16, value out w [2][F] bf16,
  *   policy out bias [7] f32, value out bias [2] f32
  *
- *   abi_consumer_nn WEIGHTS N_GAMES N_SLOTS N_MCTS_ITERATIONS
+ *   abi_consumer_nn WEIGHTS N_GAMES N_SLOTS N_MCTS_ITERATIONS [native]
  * prints the samples in the format of abi_consumer.c; the test compares them with play_games(evaluator=net).
+ * With "native" the whole job is ONE call, c4_play_games_bf16 (the library's own host loop: paired sessions in one HIP graph,
+ * tail narrowing, records merged in request order) -- what a Rust host binds to replace the body of self_play() outright.
  */
 #include <inttypes.h>
 #include <stdio.h>
@@ -93,6 +95,40 @@ int main(int argc, char** argv) {
   for (uint32_t i = 0; i < V; i++) { NEXT(vw[i]); NEXT(vb[i]); }
   NEXT(pow_); NEXT(vow); NEXT(pob); NEXT(vob);
   fclose(f);
+
+  if (argc > 5 && strcmp(argv[5], "native") == 0) {
+    c4_network_bf16 net;
+    memset(&net, 0, sizeof net);
+    net.channels = channels; net.n_blocks = n_blocks;
+    net.tower_w0 = tw0; net.tower_w = tw; net.tower_bias = (const float*)tbias;
+    net.w1 = w1; net.b1 = (const float*)b1;
+    net.n_policy_hidden = P; net.n_value_hidden = V;
+    for (uint32_t i = 0; i < P; i++) { net.policy_w[i] = pw[i]; net.policy_b[i] = (const float*)pb[i]; }
+    for (uint32_t i = 0; i < V; i++) { net.value_w[i] = vw[i]; net.value_b[i] = (const float*)vb[i]; }
+    net.policy_out_w = pow_; net.value_out_w = vow; net.policy_out_b = (const float*)pob; net.value_out_b = (const float*)vob;
+    c4_play_options opt;
+    memset(&opt, 0, sizeof opt);
+    opt.resident_games = G;
+    c4_game_metadata* reqs = (c4_game_metadata*)calloc(n_games ? n_games : 1, sizeof *reqs);
+    for (uint64_t i = 0; i < n_games; i++) reqs[i].game_id = 900 + i;
+    uint32_t* counts = (uint32_t*)calloc(n_games ? n_games : 1, sizeof *counts);
+    const uint64_t cap = n_games * C4_MAX_SAMPLES_PER_GAME;
+    c4_sample_rec* recs = (c4_sample_rec*)calloc(cap ? cap : 1, sizeof *recs);
+    uint64_t n = 0;
+    c4_counters c;
+    c4_play_phases ph;
+    C4(c4_play_games_bf16(reqs, n_games, n_iter, 6.6f, 0.01f, &net, &opt, counts, recs, cap, &n, &c, &ph));
+    printf("games %" PRIu64 " sims %" PRIu64 " samples %" PRIu64 " expansions %" PRIu64 "\n", c.games_done, c.sims, c.samples, c.expansions);
+    for (uint64_t i = 0; i < n; i++) {
+      const c4_sample_rec* r = recs + i;
+      printf("%" PRIu64 " %u %u %" PRIx64 " %" PRIx64, r->game_id, r->meta & 0xFFFFu, r->meta >> 16, r->mask, r->value);
+      for (int k = 0; k < 7; k++) printf(" %08x", bits(r->policy[k]));
+      printf(" %08x %08x\n", bits(r->q_penalty), bits(r->q_no_penalty));
+    }
+    fprintf(stderr, "native: %u session(s), %u resident games, %" PRIu64 " rounds, %u graph capture(s)\n", ph.sessions, ph.resident_games, ph.rounds, ph.graph_captures);
+    free(recs); free(counts); free(reqs);
+    return 0;
+  }
 
   c4_config cfg;
   memset(&cfg, 0, sizeof cfg);

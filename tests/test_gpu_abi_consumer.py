@@ -114,3 +114,8 @@ def test_c_host_runs_the_network_itself(tmp_path, blocks, channels, pol, val):
             for r_ in res.results}
     assert head["games"] == n_games and head["samples"] == stats["samples"] and head["expansions"] == stats["expansions"]
     assert got == want
+    # ... and the same job as ONE call from C: c4_play_games_bf16, the library's own host loop (round 6)
+    r = subprocess.run([exe, path, str(n_games), str(n_slots), str(n_iter), "native"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    head2, got2 = _parse(r.stdout)
+    assert head2 == head and got2 == want

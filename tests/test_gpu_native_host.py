@@ -1,0 +1,92 @@
+"""`c4_play_games_bf16` (include/c4a0_hip.h, c4a0_amd/csrc/c4_selfplay_host.hip): the body of the reference's `self_play()`
+(rust/src/self_play.rs:39-129) as ONE native call -- sessions, streams, the paired HIP graph, completion polling, tail narrowing,
+the merged hand-over.  It must return, byte for byte, what the Python loop of `play_games(evaluator=InferenceNet)` returns (which
+the rest of the suite holds to the oracle), for every way the job can be shaped."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _net(blocks, channels, pol=4, val=2, seed=1337):
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+
+    torch.manual_seed(seed)
+    return InferenceNet(ConnectFourNet(ModelConfig(blocks, channels, pol, val)), torch.device("cuda:0"), dtype=torch.bfloat16)
+
+
+def _both(net, n_games, n_iter, native_kw=None, **kw):
+    import c4a0_amd
+    from c4a0_amd.native import play_games_native
+
+    reqs = [c4a0_amd.GameMetadata(7000 + 3 * i, 0, 0) for i in range(n_games)]
+    st_n, st_p = {}, {}
+    got = play_games_native(reqs, 4096, n_iter, 6.6, 0.01, net, stats=st_n, **dict(kw, **(native_kw or {})))
+    want = c4a0_amd.play_games(reqs, 4096, n_iter, 6.6, 0.01, evaluator=net, stats=st_p, **kw)
+    (r1, c1), (r2, c2) = got.to_records(), want.to_records()
+    assert np.array_equal(c1, c2) and r1.tobytes() == r2.tobytes()
+    for k in ("sims", "select_levels", "backup_nodes", "expansions", "moves", "games_done", "samples"):
+        assert st_n[k] == st_p[k], k
+    assert st_n["games_done"] == n_games and st_n["error"] == 0
+    return st_n, st_p
+
+
+@pytest.mark.parametrize("blocks,channels,pol,val", [(1, 32, 4, 2), (2, 64, 2, 3), (1, 32, 2, 2)])
+def test_one_session_small_jobs(blocks, channels, pol, val):
+    """One session alone (fewer than 2 048 resident games): refill from the queue, tiles chosen for a session alone, narrowing."""
+    net = _net(blocks, channels, pol, val)
+    st, _ = _both(net, 200, 20, resident_games=64)
+    assert st["concurrent_sessions"] == 1 and st["n_slots"] == 64
+    st, _ = _both(net, 700, 12, resident_games=600)
+    assert st["rows_at_end"] < 600                                  # narrowed in the tail
+
+
+def test_two_paired_sessions_with_refill_and_tail():
+    """The product shape in small: 4 096 resident games as two paired sessions in one graph, 6 000 games (slots refilled), the tail
+    narrowed several times; also with other graph lengths (the records do not depend on them)."""
+    net = _net(4, 32)
+    st, st_p = _both(net, 6000, 16, resident_games=4096)
+    assert st["concurrent_sessions"] == 2 and st["n_slots"] == 4096 and st["rows_at_end"] < 4096
+    assert st["phases"]["graph_captures"] >= 2
+    _both(net, 3000, 10, resident_games=2048, native_kw=dict(steps_per_graph=5, tail_steps_per_graph=3))
+
+
+@pytest.mark.parametrize("ext", ["dirichlet", "cache", "reclaim"])
+def test_extensions_and_reclaimed_arenas(ext):
+    net = _net(1, 32, 2, 2)
+    if ext == "dirichlet":
+        _both(net, 900, 16, resident_games=800, dirichlet=(0.3, 0.25), concurrent_sessions=2)
+    elif ext == "cache":
+        st, _ = _both(net, 900, 16, resident_games=800, eval_cache_entries=1 << 16, concurrent_sessions=2)
+        assert st["eval_cache_hits"] > 0
+    else:
+        n, period = 24, 4
+        half = n + 2 + 8 + 2 * (2 * period * 2 + 16) + 6
+        st, _ = _both(net, 700, n, resident_games=600, concurrent_sessions=2, reclaim=True, reclaim_period=period, blocks_per_slot=2 * half)
+        assert st["reclaim_passes"] > 700
+
+
+def test_default_shapes_and_errors():
+    """No options at all: the library sizes the job itself (one session for a small job); empty jobs; multi-model requests and
+    networks the kernels do not take are refused; a too-small record buffer reports what is needed."""
+    import ctypes as C
+
+    import c4a0_amd
+    from c4a0_amd import _lib
+    from c4a0_amd.native import network_struct, play_games_native
+
+    net = _net(1, 32)
+    st, _ = _both(net, 300, 10)
+    assert st["n_slots"] == 300 and st["concurrent_sessions"] == 1
+    assert play_games_native([], 64, 10, 6.6, 0.01, net).results == []
+    with pytest.raises(TypeError):
+        play_games_native([c4a0_amd.GameMetadata(0, 1, 2)], 64, 10, 6.6, 0.01, net)
+    L, ns = _lib.lib(), network_struct(net)
+    reqs = np.zeros((40, 3), dtype=np.uint64)
+    reqs[:, 0] = np.arange(40)
+    counts, recs, n = np.zeros(40, np.uint32), np.zeros(40, dtype=np.dtype("V64")), C.c_uint64()
+    rc = L.c4_play_games_bf16(reqs.ctypes.data, 40, 8, 6.6, 0.01, C.byref(ns), None, counts.ctypes.data, recs.ctypes.data, 40, C.byref(n), None, None)
+    assert rc == _lib.ERR_BAD_ARG and n.value == counts.sum() > 40 and b"room for 40" in L.c4_last_error_string()
+    ns.channels = 48
+    assert L.c4_play_games_bf16(reqs.ctypes.data, 40, 8, 6.6, 0.01, C.byref(ns), None, counts.ctypes.data, recs.ctypes.data, 40, C.byref(n), None, None) == _lib.ERR_BAD_ARG

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Merge the per-pass summaries of tools/profile/run_r03_eval_pmc.sh into one JSON per backend with the
+"""Merge the per-pass summaries of tools/profile/run_eval_pmc.sh into one JSON per backend with the
 derived figures the bench line quotes (MFMA busy fraction of the evaluator's kernels).
     python tools/profile/merge_eval_pmc.py gpurun_out/<tag>_evalpmc_M2048 > profiles/r03_evaluator_pmc.json"""
 import csv
