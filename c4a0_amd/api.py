@@ -294,7 +294,11 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
     # Device evaluators that are pure device code: the resident games are split over sessions that run
     # concurrently on their own streams (session.run_sessions), two by default when each half still
     # fills the GEMMs.  Which session plays a game does not change its samples.
-    parts = int(concurrent_sessions) if concurrent_sessions else (2 if graph_safe and n_slots >= 2048 else 1)
+    # ... unless the job is ONE generation (no more requests than slots: nothing is ever refilled, the whole job is its tail): below
+    # 2 048 rows a single chain's round is shorter than two paired chains' (57 against 65 us at 1 024 games, profiles/r06_whole_call.txt
+    # (d)), which outweighs the full-width rounds a pair plays faster (104 against 120 us at 4 096): 4 096 games on 4 096 slots take
+    # 0.280 s with one session, 0.297 with two (40 960 games on 4 096 slots: 1.77 against 1.62 -- there the pair wins).
+    parts = int(concurrent_sessions) if concurrent_sessions else (2 if graph_safe and n_slots >= 2048 and len(reqs) > n_slots else 1)
     if parts > 1 and not graph_safe:
         raise TypeError("concurrent_sessions > 1 needs a graph-safe device evaluator (c4a0_amd.nn.InferenceNet)")
     parts = max(1, min(parts, n_slots))
@@ -311,8 +315,11 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
     elif parts == 2:
         steps_per_graph = 64 if est_rounds >= 4000 else (32 if est_rounds >= 1500 else 8)
         tail_steps_per_graph = 16 if steps_per_graph >= 32 else 8
-    else:
-        steps_per_graph = tail_steps_per_graph = 32 if (len(reqs) >= 32 * n_slots or int(n_mcts_iterations) >= 400) else 8
+    elif est_rounds >= 10000:     # one session, a long job (the reference's default job: 37 000 rounds): the replay boundary matters all the way
+        steps_per_graph = tail_steps_per_graph = 32
+    else:                         # one session, e.g. one generation of config 2's games (3 100 rounds)
+        steps_per_graph = 32 if est_rounds >= 1500 else 8
+        tail_steps_per_graph = 16 if steps_per_graph >= 32 else 8
     if hasattr(evaluator, "latency_mode"):   # InferenceNet: tile choice of the narrow layers, alone vs beside another session
         evaluator.latency_mode = parts == 1
     phases = {} if stats is not None else None
@@ -340,7 +347,7 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
             steps = sessions[0].run(_MultiModelEvaluator(sessions[0], evaluator), phases=phases)
         else:
             # a c4a0_amd.nn.InferenceNet is pure device code: replay it and the step kernel from a HIP graph
-            steps = sessions[0].run(evaluator, steps_per_graph=steps_per_graph, phases=phases)
+            steps = sessions[0].run(evaluator, steps_per_graph=steps_per_graph, phases=phases, tail_steps_per_graph=tail_steps_per_graph)
         t_drain0 = time.perf_counter()
         pieces = []
         merge_on_device = on_device or parts > 1   # several sessions: interleave their records on the device, ONE transfer to the host

@@ -206,16 +206,17 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
       while (resident > 4096 && resident * per_slot > free_b / 4) resident /= 2;
   }
   resident = std::min<uint64_t>(resident, n_games);
-  uint32_t n_parts = opt.concurrent_sessions ? opt.concurrent_sessions : (resident >= 2048 ? 2u : 1u);
+  // two paired sessions from 2 048 resident games -- unless the job is one generation (nothing is ever refilled: it is all tail, and
+  // below 2 048 rows one chain's round is shorter than two paired chains'; c4a0_amd/api.py _play has the measurements)
+  uint32_t n_parts = opt.concurrent_sessions ? opt.concurrent_sessions : ((resident >= 2048 && n_games > resident) ? 2u : 1u);
   if (n_parts > 2) return fail(C4_ERR_BAD_ARG, "c4_play_games_bf16: one session, or two paired ones");
   n_parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_parts, resident));
   const bool extensions = opt.dirichlet_epsilon > 0.0f || opt.eval_cache_entries != 0;
   const bool fused = !extensions;                       // what c4_session_step_head_out accepts (per-launch timing is switched off below)
   const uint64_t est_rounds = ((n_games + resident - 1) / resident) * 15ull * std::max<uint32_t>(1u, n_mcts_iterations);
   uint32_t steady = opt.steps_per_graph, tail = opt.tail_steps_per_graph;
-  if (steady == 0) steady = n_parts == 2 ? (est_rounds >= 4000 ? 64u : (est_rounds >= 1500 ? 32u : 8u))
-                                         : ((n_games >= 32 * resident || n_mcts_iterations >= 400) ? 32u : 8u);
-  if (tail == 0) tail = n_parts == 2 ? (steady >= 32 ? 16u : 8u) : steady;
+  if (steady == 0) steady = n_parts == 2 ? (est_rounds >= 4000 ? 64u : (est_rounds >= 1500 ? 32u : 8u)) : (est_rounds >= 1500 ? 32u : 8u);
+  if (tail == 0) tail = (n_parts == 1 && est_rounds >= 10000) ? steady : (steady >= 32 ? 16u : 8u);   // a long one-session job keeps its long graphs
 
   Job j;
   j.parts.resize(n_parts);

@@ -336,12 +336,13 @@ class DeviceSession:
         return self.rows != before
 
     def run(self, evaluator: DeviceEvaluator, max_steps: Optional[int] = None, poll_every: int = 16,
-            on_step: Optional[Callable[[int], None]] = None, steps_per_graph: int = 0, phases: Optional[dict] = None) -> int:
+            on_step: Optional[Callable[[int], None]] = None, steps_per_graph: int = 0, phases: Optional[dict] = None,
+            tail_steps_per_graph: int = 0) -> int:
         """Play all games set by set_games() to completion.  Returns the number of steps.
 
         steps_per_graph > 0 replays a HIP graph of that many (evaluator, step) rounds per host
-        iteration -- for evaluators that are pure device code (no host callbacks).  phases (a dict) receives where the wall
-        time went, as session._run_pair fills it."""
+        iteration -- for evaluators that are pure device code (no host callbacks); from the first narrowing of the tail on
+        tail_steps_per_graph rounds (0 = the same).  phases (a dict) receives where the wall time went, as session._run_pair fills it."""
         self.bind()
         self.start()
         steps = 0
@@ -388,6 +389,7 @@ class DeviceSession:
                         self.narrow_if_worthwhile(asynchronous=bool(getattr(evaluator, "batch_invariant", False))):
                     inflight.clear()
                     t_c = time.perf_counter()
+                    steps_per_graph = int(tail_steps_per_graph or steps_per_graph)
                     graph = self.capture_steps(evaluator, steps_per_graph)   # the old graph carries the old width
                     if phases is not None:
                         phases["recapture_s"] += time.perf_counter() - t_c

@@ -79,6 +79,8 @@ def test_default_shapes_and_errors():
     net = _net(1, 32)
     st, _ = _both(net, 300, 10)
     assert st["n_slots"] == 300 and st["concurrent_sessions"] == 1
+    st, st_p = _both(net, 2500, 6)                                  # one generation (no refill): ONE session although 2 048 rows would pair
+    assert st["n_slots"] == 2500 and st["concurrent_sessions"] == 1 == st_p["concurrent_sessions"]
     assert play_games_native([], 64, 10, 6.6, 0.01, net).results == []
     with pytest.raises(TypeError):
         play_games_native([c4a0_amd.GameMetadata(0, 1, 2)], 64, 10, 6.6, 0.01, net)
