@@ -497,3 +497,32 @@ def test_request_table_and_resident_games_defaults():
     got = {n: default_resident_games(n, 100, True) for n in (1, 100, 4096, 4097, 16384, 32767, 32768, 40960, 65535, 65536, 10 ** 6)}
     assert got == {1: 1, 100: 100, 4096: 4096, 4097: 4096, 16384: 4096, 32767: 4096, 32768: 8192, 40960: 8192, 65535: 8192, 65536: 16384, 10 ** 6: 16384}
     assert default_resident_games(10 ** 6, 100, False) == 4096
+
+
+def test_ctypes_structures_match_the_headers_layout_as_gcc_sees_it(tmp_path):
+    """Every structure the ctypes binding hands to / reads from the library has the size and the field offsets gcc computes from
+    include/c4a0_hip.h (a consumer written in another language mirrors the same layout: INTEGRATION.md)."""
+    import shutil
+    import subprocess
+
+    from c4a0_amd import _lib
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = [("c4_game_metadata", _lib.GameMetadataC), ("c4_sample_rec", _lib.SampleRec), ("c4_config", _lib.Config), ("c4_counters", _lib.Counters),
+             ("c4_network_bf16", _lib.NetworkBf16), ("c4_play_options", _lib.PlayOptions), ("c4_play_phases", _lib.PlayPhases)]
+    lines = []
+    for cname, cls in pairs:
+        lines.append(f'printf("{cname} %zu", sizeof({cname}));')
+        for fname, _t in cls._fields_:
+            lines.append(f'printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('printf("\\n");')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "c4a0_hip.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for (cname, cls), line in zip(pairs, out):
+        f = line.split()
+        assert f[0] == cname and int(f[1]) == C.sizeof(cls), (cname, f[1], C.sizeof(cls))
+        assert [int(x) for x in f[2:]] == [getattr(cls, n).offset for n, _t in cls._fields_], cname

@@ -24,12 +24,12 @@ def test_time_boxed_fuzz_parity_fixed_seed(seed, seconds, env):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), str(seconds), str(seed)], cwd=ROOT, capture_output=True,
                        text=True, timeout=600, env=dict(os.environ, **env))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    m = re.search(r"fuzz parity ok: (\d+) jobs \((\d+) of them through the numpy callback.*?; (\d+) with the bf16 network.*?; (\d+) on arenas reclaimed.*?; (\d+) with Dirichlet noise\), (\d+) games", r.stdout)
+    m = re.search(r"fuzz parity ok: (\d+) jobs \((\d+) of them through the numpy callback.*?; (\d+) with the bf16 network.*?; (\d+) through the native host loop.*?; (\d+) on arenas reclaimed.*?; (\d+) with Dirichlet noise\), (\d+) games", r.stdout)
     assert m, r.stdout[-1500:]
-    jobs, cb_jobs, net_jobs, reclaimed_jobs, dirichlet_jobs, games = (int(g) for g in m.groups())
+    jobs, cb_jobs, net_jobs, native_jobs, reclaimed_jobs, dirichlet_jobs, games = (int(g) for g in m.groups())
     evidence(f"fuzz seed {seed}: " + r.stdout.strip().splitlines()[-1])
     # an MI355X runs ~7 jobs per second of the mix (profiles/r04_fuzz_parity.txt: 4 132 jobs in 10 minutes); far fewer means the soak did not really run
     if env:
         assert jobs >= 40 and reclaimed_jobs >= 0.5 * jobs and dirichlet_jobs == jobs and games >= 300, r.stdout[-500:]
     else:
-        assert jobs >= 40 and cb_jobs >= 5 and net_jobs >= 3 and reclaimed_jobs >= 6 and games >= 400, r.stdout[-500:]
+        assert jobs >= 40 and cb_jobs >= 5 and net_jobs >= 3 and native_jobs >= 3 and reclaimed_jobs >= 6 and games >= 400, r.stdout[-500:]

@@ -106,6 +106,49 @@ def fused_job():
     n_games_total += n_games
 
 
+n_native_jobs = 0
+
+
+def native_job():
+    """The library's own host loop (c4_play_games_bf16: sessions, paired graph, narrowing, merged hand-over in C++) against an eager
+    DeviceSession.run of the same games (stand-alone kernels launched from Python): byte-identical records for random networks,
+    widths, one / two sessions, graph lengths, and with the extensions / reclaimed arenas."""
+    global n_jobs, n_games_total, n_native_jobs
+    from c4a0_amd.native import play_games_native
+    from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
+    from c4a0_amd.results import GameMetadata, results_from_records
+    heads = rng.choice([(2, 2), (4, 2), (3, 3)])
+    key = ("native",) + heads
+    if key not in _nets:
+        torch.manual_seed(hash(key) & 0xFFFF)
+        _nets[key] = InferenceNet(ConnectFourNet(ModelConfig(rng.choice([1, 2]), 32, *heads)), torch.device("cuda:0"), dtype=torch.bfloat16)
+    net = _nets[key]
+    n_games = rng.choice([1, 5, 16, 17, 40, 130, 600])
+    n_slots = rng.choice([1, 7, 8, 15, 16, 33, 100, 300])
+    n_iter = rng.choice([2, 5, 12, 30])
+    sessions = rng.choice([1, 1, 2])
+    dirichlet = rng.choice([None, None, (0.3, 0.25)])
+    cache = rng.choice([0, 0, 4096])
+    rperiod = rng.choice([1, 2, 5])
+    rkw = dict(reclaim=True, reclaim_period=rperiod, blocks_per_slot=2 * (n_iter + 16 + 2 * (16 * rperiod + 16) + rng.choice([0, 3, 40]))) if rng.random() < 0.3 else {}
+    reqs = [(9000 + 5 * i, 0, 0) for i in range(n_games)]
+    cfg = dict(native=True, heads=heads, n_games=n_games, n_slots=n_slots, n_iter=n_iter, sessions=sessions, dirichlet=dirichlet, cache=cache, reclaim=rkw)
+    got = play_games_native([GameMetadata(*r) for r in reqs], 64, n_iter, 6.6, 0.01, net, resident_games=n_slots, concurrent_sessions=sessions,
+                            steps_per_graph=rng.choice([0, 1, 3, 8]), tail_steps_per_graph=rng.choice([0, 1, 4]), dirichlet=dirichlet,
+                            eval_cache_entries=cache, **rkw)
+    s = DeviceSession(min(n_slots, n_games), n_iter, 6.6, 0.01, planes_dtype=torch.bfloat16)
+    s.set_games(reqs)
+    if dirichlet:
+        s.set_dirichlet(*dirichlet)
+    s.run(net)                                   # eager: evaluate() + step(), the two stand-alone kernels, no cache
+    want = results_from_records([GameMetadata(*r) for r in reqs], s.drain_samples(), s.sample_counts())
+    s.close()
+    assert got.to_records()[0].tobytes() == want.to_records()[0].tobytes(), cfg
+    n_jobs += 1
+    n_native_jobs += 1
+    n_games_total += n_games
+
+
 while time.time() - t0 < budget:
     r = rng.random()
     if r < 0.25 and "FUZZ_TREE_ONLY" not in os.environ:
@@ -113,6 +156,9 @@ while time.time() - t0 < budget:
         continue
     if r < 0.45 and "FUZZ_TREE_ONLY" not in os.environ:
         fused_job()
+        continue
+    if r < 0.55 and "FUZZ_TREE_ONLY" not in os.environ:
+        native_job()
         continue
     n_games = rng.choice([1, 2, 3, 7, 8, 9, 17, 40, 100])
     n_slots = rng.choice([1, 2, 7, 8, 9, 16, 33])
@@ -166,5 +212,5 @@ while time.time() - t0 < budget:
     assert got == oracle_samples_by_game(want), cfg
     n_jobs += 1
     n_games_total += len(ids)
-print(f"fuzz parity ok: {n_jobs} jobs ({n_cb_jobs} of them through the numpy callback, one or several models; {n_fused_jobs} with the bf16 network, fused graph path vs eager; {n_reclaimed_jobs} on arenas reclaimed during play; {n_dirichlet_jobs} with Dirichlet noise), {n_games_total} games in {time.time() - t0:.0f} s; "
+print(f"fuzz parity ok: {n_jobs} jobs ({n_cb_jobs} of them through the numpy callback, one or several models; {n_fused_jobs} with the bf16 network, fused graph path vs eager; {n_native_jobs} through the native host loop c4_play_games_bf16 vs eager; {n_reclaimed_jobs} on arenas reclaimed during play; {n_dirichlet_jobs} with Dirichlet noise), {n_games_total} games in {time.time() - t0:.0f} s; "
       f"{n_errs} more jobs ended in the same panic on both sides")
