@@ -279,8 +279,10 @@ def product_legs(args, device, real_stdout):
       whole_call_10xG          40 960 games (10 x G, SURVEY 8d's own N for config 2), resident games chosen by the library
       whole_call_10xG_4096     the same job on exactly 4 096 slots (config 2's "4 096 concurrent games") -- and its records must equal the first's
       one_generation_4096      4 096 games on 4 096 slots: what each rank of BASELINE config 3 really runs (no refill: the whole job is tail)
-      native_host_loop_10xG    the same 40 960-game job through `c4_play_games_bf16`, the library's own host loop (one native call: what a
-                               Rust host of the reference binds in place of self_play()); its records must equal the Python loop's
+      python_host_loop_10xG    the same 40 960-game job driven by the Python loop of c4a0_amd/session.py (host_loop="python": what every other
+                               kind of evaluator gets) instead of `c4_play_games_bf16`, the library's own host loop, which `play_games` takes
+                               by itself for an InferenceNet (one native call: what a Rust host of the reference binds in place of
+                               self_play()); the two must return the same records
       eval_cache_10xG          EXTENSION (off by default, not the reference's algorithm: it evaluates every leaf and dedups inside a
                                batch only, self_play.rs:203-208): leaves whose position the evaluator has already answered skip the
                                evaluator row; records must equal the cache-off job's -- all of them are compared
@@ -298,7 +300,7 @@ def product_legs(args, device, real_stdout):
     c4a0_amd.play_games(reqs[:64], 4096, 20, 6.6, 0.01, evaluator=net)      # untimed: code objects, LDS opt-ins, allocator warm-up
     c4a0_amd.play_games(reqs[:G], 4096, 10, 6.6, 0.01, evaluator=net)       # ... and the tree arena of the big shapes (kept by the library between sessions)
 
-    def call(n, native=False, **kw):
+    def call(n, **kw):
         # every shape is played TWICE and the second call is the one reported (a training loop calls play_games every generation): the
         # first call of a shape also pays for what the process keeps afterwards -- the tree arena, PyTorch's device and pinned blocks for
         # the hand-over (a 48 MB transfer into fresh pageable memory: 0.05-0.2 s once) -- and is reported beside it as first_call_seconds
@@ -307,10 +309,7 @@ def product_legs(args, device, real_stdout):
             st = {}
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            if native:
-                res = c4a0_amd.play_games_native(reqs[:n], 4096, 100, 6.6, 0.01, net, stats=st, **kw)
-            else:
-                res = c4a0_amd.play_games(reqs[:n], 4096, 100, 6.6, 0.01, evaluator=net, stats=st, **kw)
+            res = c4a0_amd.play_games(reqs[:n], 4096, 100, 6.6, 0.01, evaluator=net, stats=st, **kw)
             dt = time.perf_counter() - t0
             first = dt if first is None else first
         t0 = time.perf_counter()
@@ -318,7 +317,7 @@ def product_legs(args, device, real_stdout):
         dt_dump = time.perf_counter() - t0
         recs, counts = res.to_records()
         ph = st["phases"]
-        return recs, {"games": n, "resident_games": st["n_slots"], "seconds": dt, "first_call_seconds": first, "games_per_s": n / dt, "sims_per_s": st["sims"] / dt, "rounds": st["steps"],
+        return recs, {"games": n, "host_loop": st["host_loop"], "sessions": st["concurrent_sessions"], "resident_games": st["n_slots"], "seconds": dt, "first_call_seconds": first, "games_per_s": n / dt, "sims_per_s": st["sims"] / dt, "rounds": st["steps"],
                       "samples": int(len(recs)), "phases_s": {k: ph[k] for k in ("setup_s", "start_and_capture_s", "steady_s", "tail_s", "drain_s")},
                       "tail_share_of_call": ph["tail_s"] / dt, "graph_captures": ph["graph_captures"], "rounds_until_all_started": ph["rounds_until_all_started"],
                       "pickle_seconds": dt_dump, "pickle_bytes": len(blob), "games_per_s_play_plus_pickle": n / (dt + dt_dump),
@@ -330,9 +329,9 @@ def product_legs(args, device, real_stdout):
     again, out["whole_call_10xG_4096"] = call(10 * G, resident_games=G)
     out["whole_call_10xG_4096"]["records_identical_to_whole_call_10xG"] = bool(again.tobytes() == base.tobytes())
     _r, out["one_generation_4096"] = call(G, resident_games=G)
-    nat, out["native_host_loop_10xG"] = call(10 * G, native=True)
-    out["native_host_loop_10xG"]["records_identical_to_whole_call_10xG"] = bool(nat.tobytes() == base.tobytes())
-    out["native_host_loop_10xG"]["entry_point"] = "c4_play_games_bf16 (include/c4a0_hip.h): sessions, graphs, polling, narrowing and the merged hand-over inside one C call"
+    py, out["python_host_loop_10xG"] = call(10 * G, host_loop="python")
+    out["python_host_loop_10xG"]["records_identical_to_whole_call_10xG"] = bool(py.tobytes() == base.tobytes())
+    out["whole_call_10xG"]["entry_point"] = "c4_play_games_bf16 (include/c4a0_hip.h): sessions, graphs, polling, narrowing and the merged hand-over inside one C call"
     cached, out["eval_cache_10xG"] = call(10 * G, eval_cache_entries=1 << 24)
     out["eval_cache_10xG"]["samples_identical"] = bool(cached.tobytes() == base.tobytes())
     out["eval_cache_10xG"]["samples_compared"] = int(len(base))

@@ -215,7 +215,7 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
                planes_dtype: Optional[torch.dtype] = None, blocks_per_slot: int = 0,
                stats: Optional[dict] = None, dirichlet: Optional[tuple] = None,
                concurrent_sessions: Optional[int] = None, eval_cache_entries: int = 0,
-               reclaim: Optional[bool] = None, reclaim_period: int = 0) -> PlayGamesResult:
+               reclaim: Optional[bool] = None, reclaim_period: int = 0, host_loop: Optional[str] = None) -> PlayGamesResult:
     """Play every game of `reqs` to the end with MCTS self-play on the GPU and return the
     training samples (reference pybridge.rs:20-53).  Results are in `reqs` order (the
     reference's order is thread-finishing order, self_play.rs:116).
@@ -226,7 +226,14 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
 
     Any `n_mcts_iterations` up to 32 200 is accepted, like the reference's heap-allocated tree (mcts.rs:187-206, 332-355): above
     1 000 iterations per move the tree arenas are reclaimed while the games are played (`reclaim=` True / False forces it on /
-    off, `DeviceSession`; the samples are the same either way)."""
+    off, `DeviceSession`; the samples are the same either way).
+
+    host_loop: who drives the rounds.  With an unmodified bf16 `c4a0_amd.nn.InferenceNet` the whole job runs inside ONE call of the
+    library (`c4_play_games_bf16`, csrc/c4_selfplay_host.hip: sessions, the paired HIP graph, polling, narrowing, the merged
+    hand-over in C++ -- as the reference's `self_play()` is compiled code, self_play.rs:39-129); every other evaluator (numpy
+    callbacks, arbitrary device callables, tournaments, subclasses that override `forward`) is driven by the Python loop of
+    c4a0_amd/session.py, which implements the same schedule.  None = that choice; "python" forces the Python loop, "native"
+    insists on the library's (TypeError if the evaluator is not one it can run).  Same records either way."""
     reqs = list(reqs)
     if py_eval_pos_cb is not None and evaluator is None and getattr(py_eval_pos_cb, "device_evaluator", None) is not None:
         evaluator, py_eval_pos_cb = py_eval_pos_cb.device_evaluator, None
@@ -237,7 +244,7 @@ def play_games(reqs: Sequence[GameMetadata], max_nn_batch_size: int, n_mcts_iter
     recs, counts = _play(metas, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator,
                          device=device, resident_games=resident_games, planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot, stats=stats,
                          dirichlet=dirichlet, concurrent_sessions=concurrent_sessions, eval_cache_entries=eval_cache_entries, on_device=False,
-                         reclaim=reclaim, reclaim_period=reclaim_period)
+                         reclaim=reclaim, reclaim_period=reclaim_period, host_loop=host_loop)
     return results_from_records(metas, recs, counts)
 
 
@@ -276,9 +283,67 @@ def merge_parts(n_games: int, parts):
     return out, counts
 
 
+def _native_loop_refusal(evaluator, device, planes_dtype, concurrent_sessions) -> Optional[str]:
+    """None if `c4_play_games_bf16` can play this job exactly as the Python loop would, else the reason it cannot."""
+    from .nn import InferenceNet
+
+    if not isinstance(evaluator, InferenceNet):
+        return "the evaluator is not a c4a0_amd.nn.InferenceNet"
+    if not evaluator.fused_step_ok:           # (a subclass that overrides forward / __call__ must see every evaluation)
+        return "the evaluator overrides InferenceNet.forward, or does not run on the hand-written kernels"
+    if evaluator.path != "hip" or evaluator.dtype != torch.bfloat16 or evaluator.merged_w1 is None:
+        return "the library's loop takes a bf16 network on the hand-written kernels whose heads both have a hidden layer"
+    if len(evaluator.pol_w) - 2 > 8 or len(evaluator.val_w) - 2 > 8:
+        return "more than 8 further hidden layers in a head"
+    if evaluator.gemm_config != (0, 0) or evaluator.tower_config or not evaluator.use_loader_waves or not evaluator.wide_tiles_r5 or evaluator.stage_hook is not None:
+        return "the evaluator carries a measurement switch (tile configuration, stage hook)"
+    if concurrent_sessions not in (None, 0, 1, 2):
+        return "more than two concurrent sessions"
+    if planes_dtype not in (None, torch.bfloat16):
+        return "planes_dtype must be bfloat16"
+    if device is not None and torch.device(device) != evaluator.device and not (torch.device(device).index is None and torch.device(device).type == "cuda"):
+        return "device= names another device than the evaluator's"
+    return None
+
+
+def _play_native(reqs, n_mcts_iterations, c_exploration, c_ply_penalty, net, resident_games, blocks_per_slot, stats, dirichlet, concurrent_sessions,
+                 eval_cache_entries, reclaim, reclaim_period):
+    """`_play` through the library's own host loop (c4_play_games_bf16): (records, counts) in request order."""
+    import ctypes as C
+
+    from . import _lib
+    from .native import network_struct
+    from .session import SAMPLE_DTYPE
+
+    n = len(reqs)
+    ns = network_struct(net)
+    opt = _lib.PlayOptions()
+    opt.device = net.device.index if net.device.index is not None else torch.cuda.current_device()
+    opt.resident_games, opt.concurrent_sessions = int(resident_games or 0), int(concurrent_sessions or 0)
+    opt.blocks_per_slot, opt.reclaim_period = int(blocks_per_slot), int(reclaim_period)
+    opt.flags = _lib.FLAG_RECLAIM if reclaim else (_lib.FLAG_NO_RECLAIM if reclaim is False else 0)
+    if dirichlet is not None:
+        opt.dirichlet_alpha, opt.dirichlet_epsilon = float(dirichlet[0]), float(dirichlet[1])
+    opt.eval_cache_entries = int(eval_cache_entries)
+    counts = np.empty(n, dtype=np.uint32)
+    recs = np.empty(n * _lib.MAX_SAMPLES_PER_GAME, dtype=SAMPLE_DTYPE)      # 43 per game always suffice; untouched pages are never made resident
+    n_recs, totals, phases = C.c_uint64(), _lib.Counters(), _lib.PlayPhases()
+    tab = np.ascontiguousarray(reqs, dtype=np.uint64)
+    _lib.check(_lib.lib().c4_play_games_bf16(tab.ctypes.data, n, int(n_mcts_iterations), float(c_exploration), float(c_ply_penalty), C.byref(ns),
+                                             C.byref(opt), counts.ctypes.data, recs.ctypes.data, len(recs), C.byref(n_recs), C.byref(totals), C.byref(phases)))
+    if stats is not None:
+        ph = phases.as_dict()
+        stats.update(totals.as_dict())
+        stats.update(steps=ph["rounds"], n_slots=ph["resident_games"], rows_at_end=ph["rows_at_end"], concurrent_sessions=ph["sessions"], host_loop="native")
+        stats["phases"] = {"setup_s": ph["setup_s"], "start_and_capture_s": 0.0, "steady_s": ph["steady_s"], "tail_s": ph["tail_s"], "drain_s": ph["drain_s"],
+                           "graph_captures": ph["graph_captures"], "recapture_s_inside_steady_and_tail": ph["capture_s"],
+                           "rounds_until_all_started": ph["rounds_until_all_started"], "narrowings": []}
+    return recs[: n_recs.value], counts
+
+
 def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator, device=None,
           resident_games=None, planes_dtype=None, blocks_per_slot=0, stats=None, dirichlet=None, concurrent_sessions=None,
-          eval_cache_entries=0, on_device=False, reclaim=None, reclaim_period=0):
+          eval_cache_entries=0, on_device=False, reclaim=None, reclaim_period=0, host_loop=None):
     """Play `reqs` (a uint64[n, 3] table of ids, or GameMetadata-like objects) on ONE device.  Returns (records, counts) in request order; `records` is a numpy
     SAMPLE_DTYPE array, or with on_device=True a uint8[n, 64] tensor that never left the GPU (packed
     by k_pack_samples: what the sample all-gather of the multi-GPU path sends)."""
@@ -286,6 +351,15 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
 
     if not isinstance(reqs, np.ndarray):
         reqs = _ids_of(reqs)
+    if host_loop not in (None, "native", "python"):
+        raise ValueError('host_loop must be None, "native" or "python"')
+    if host_loop != "python" and not on_device:     # (on_device: the records stay on the GPU for the sample all-gather -- the Python loop's hand-over)
+        why = _native_loop_refusal(evaluator, device, planes_dtype, concurrent_sessions)
+        if why is None:
+            return _play_native(reqs, n_mcts_iterations, c_exploration, c_ply_penalty, evaluator, resident_games, blocks_per_slot, stats, dirichlet,
+                                concurrent_sessions, eval_cache_entries, reclaim, reclaim_period)
+        if host_loop == "native":
+            raise TypeError(f"host_loop='native': {why}")
     multi = evaluator is not None and isinstance(evaluator, dict)
     if planes_dtype is None:   # hand a bf16 network bf16 planes (0/1 are exact): no conversion kernel per step
         planes_dtype = torch.bfloat16 if getattr(evaluator, "dtype", None) == torch.bfloat16 else torch.float32
@@ -380,6 +454,7 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
             stats["n_slots"] = sum(s.n_slots for s in sessions)
             stats["rows_at_end"] = sum(s.rows for s in sessions)
             stats["concurrent_sessions"] = parts
+            stats["host_loop"] = "python"
             if evaluator is None:
                 stats["nn_positions"] = ev.nn_positions
     finally:

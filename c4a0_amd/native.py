@@ -47,7 +47,8 @@ def play_games_native(reqs: Sequence, max_nn_batch_size: int, n_mcts_iterations:
                       tail_steps_per_graph: int = 0, blocks_per_slot: int = 0, reclaim: Optional[bool] = None, reclaim_period: int = 0,
                       dirichlet: Optional[tuple] = None, eval_cache_entries: int = 0, stats: Optional[dict] = None) -> PlayGamesResult:
     """The reference's six arguments (max_nn_batch_size has no meaning in device mode: every resident game's leaf is a row) with
-    `net` in place of the callback, and `play_games`' keywords; the whole job runs inside ONE library call."""
+    `net` in place of the callback, and `play_games`' keywords plus the graph lengths; the whole job runs inside ONE library call.
+    (`play_games(evaluator=net)` takes this path by itself for an unmodified InferenceNet; this entry point insists on it.)"""
     from .api import _ids_of
     from .session import SAMPLE_DTYPE
 
@@ -79,8 +80,8 @@ def play_games_native(reqs: Sequence, max_nn_batch_size: int, n_mcts_iterations:
     if stats is not None:
         stats.update(totals.as_dict())
         ph = phases.as_dict()
-        stats.update(steps=ph["rounds"], n_slots=ph["resident_games"], rows_at_end=ph["rows_at_end"], concurrent_sessions=ph["sessions"])
+        stats.update(steps=ph["rounds"], n_slots=ph["resident_games"], rows_at_end=ph["rows_at_end"], concurrent_sessions=ph["sessions"], host_loop="native")
         stats["phases"] = {"setup_s": ph["setup_s"], "start_and_capture_s": 0.0, "steady_s": ph["steady_s"], "tail_s": ph["tail_s"], "drain_s": ph["drain_s"],
-                           "graph_captures": ph["graph_captures"], "capture_s_inside_the_other_phases": ph["capture_s"],
-                           "rounds_until_all_started": ph["rounds_until_all_started"]}
+                           "graph_captures": ph["graph_captures"], "recapture_s_inside_steady_and_tail": ph["capture_s"],
+                           "rounds_until_all_started": ph["rounds_until_all_started"], "narrowings": []}
     return results_from_records(ids, recs[: n_recs.value], counts)

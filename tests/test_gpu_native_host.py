@@ -23,7 +23,8 @@ def _both(net, n_games, n_iter, native_kw=None, **kw):
     reqs = [c4a0_amd.GameMetadata(7000 + 3 * i, 0, 0) for i in range(n_games)]
     st_n, st_p = {}, {}
     got = play_games_native(reqs, 4096, n_iter, 6.6, 0.01, net, stats=st_n, **dict(kw, **(native_kw or {})))
-    want = c4a0_amd.play_games(reqs, 4096, n_iter, 6.6, 0.01, evaluator=net, stats=st_p, **kw)
+    want = c4a0_amd.play_games(reqs, 4096, n_iter, 6.6, 0.01, evaluator=net, stats=st_p, host_loop="python", **kw)
+    assert st_n["host_loop"] == "native" and st_p["host_loop"] == "python"
     (r1, c1), (r2, c2) = got.to_records(), want.to_records()
     assert np.array_equal(c1, c2) and r1.tobytes() == r2.tobytes()
     for k in ("sims", "select_levels", "backup_nodes", "expansions", "moves", "games_done", "samples"):
@@ -65,6 +66,43 @@ def test_extensions_and_reclaimed_arenas(ext):
         half = n + 2 + 8 + 2 * (2 * period * 2 + 16) + 6
         st, _ = _both(net, 700, n, resident_games=600, concurrent_sessions=2, reclaim=True, reclaim_period=period, blocks_per_slot=2 * half)
         assert st["reclaim_passes"] > 700
+
+
+def test_play_games_takes_the_native_loop_by_itself_and_only_where_it_applies():
+    """`play_games(evaluator=InferenceNet)` runs inside the library's loop; a subclass that overrides forward (it must see every
+    evaluation), a measurement switch on the net, three sessions or a plain device callable keep the Python loop; host_loop="native"
+    insists and says why it cannot."""
+    import c4a0_amd
+    from c4a0_amd.nn import InferenceNet
+    from tests.helpers import hash_eval_torch
+
+    net = _net(1, 32)
+    reqs = [c4a0_amd.GameMetadata(i, 0, 0) for i in range(40)]
+    st = {}
+    base = c4a0_amd.play_games(reqs, 64, 8, 6.6, 0.01, evaluator=net, stats=st)
+    assert st["host_loop"] == "native" and st["games_done"] == 40
+
+    class Counting(InferenceNet):
+        calls = 0
+
+        def forward(self, *a, **k):
+            Counting.calls += 1
+            return super().forward(*a, **k)
+        __call__ = forward
+
+    cnet = Counting.__new__(Counting)
+    cnet.__dict__.update(net.__dict__)
+    for kw, ev in ((dict(), cnet), (dict(concurrent_sessions=3, resident_games=30), net), (dict(), hash_eval_torch)):
+        st = {}
+        res = c4a0_amd.play_games(reqs, 64, 8, 6.6, 0.01, evaluator=ev, stats=st, **kw)
+        assert st["host_loop"] == "python"
+        if ev is not hash_eval_torch:
+            assert res.to_records()[0].tobytes() == base.to_records()[0].tobytes()
+    assert Counting.calls > 0
+    with pytest.raises(TypeError, match="host_loop='native'"):
+        c4a0_amd.play_games(reqs, 64, 8, 6.6, 0.01, evaluator=hash_eval_torch, host_loop="native")
+    with pytest.raises(ValueError):
+        c4a0_amd.play_games(reqs, 64, 8, 6.6, 0.01, evaluator=net, host_loop="rust")
 
 
 def test_default_shapes_and_errors():

@@ -94,7 +94,7 @@ def fused_job():
     reqs = [(5000 + 3 * i, 0, 0) for i in range(n_games)]
     cfg = dict(fused=True, heads=heads, n_games=n_games, n_slots=n_slots, n_iter=n_iter)
     got = c4a0_amd.play_games([c4a0_amd.GameMetadata(*r) for r in reqs], 64, n_iter, 6.6, 0.01, evaluator=net, resident_games=n_slots,
-                              concurrent_sessions=rng.choice([1, 1, 2]))
+                              concurrent_sessions=rng.choice([1, 1, 2]), host_loop="python")   # (native_job covers the library's own loop)
     s = DeviceSession(min(n_slots, n_games), n_iter, 6.6, 0.01, planes_dtype=torch.bfloat16)
     s.set_games(reqs)
     s.run(net)                                   # eager: evaluate() + step(), the two stand-alone kernels
