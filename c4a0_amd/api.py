@@ -306,41 +306,6 @@ def _native_loop_refusal(evaluator, device, planes_dtype, concurrent_sessions) -
     return None
 
 
-def _play_native(reqs, n_mcts_iterations, c_exploration, c_ply_penalty, net, resident_games, blocks_per_slot, stats, dirichlet, concurrent_sessions,
-                 eval_cache_entries, reclaim, reclaim_period):
-    """`_play` through the library's own host loop (c4_play_games_bf16): (records, counts) in request order."""
-    import ctypes as C
-
-    from . import _lib
-    from .native import network_struct
-    from .session import SAMPLE_DTYPE
-
-    n = len(reqs)
-    ns = network_struct(net)
-    opt = _lib.PlayOptions()
-    opt.device = net.device.index if net.device.index is not None else torch.cuda.current_device()
-    opt.resident_games, opt.concurrent_sessions = int(resident_games or 0), int(concurrent_sessions or 0)
-    opt.blocks_per_slot, opt.reclaim_period = int(blocks_per_slot), int(reclaim_period)
-    opt.flags = _lib.FLAG_RECLAIM if reclaim else (_lib.FLAG_NO_RECLAIM if reclaim is False else 0)
-    if dirichlet is not None:
-        opt.dirichlet_alpha, opt.dirichlet_epsilon = float(dirichlet[0]), float(dirichlet[1])
-    opt.eval_cache_entries = int(eval_cache_entries)
-    counts = np.empty(n, dtype=np.uint32)
-    recs = np.empty(n * _lib.MAX_SAMPLES_PER_GAME, dtype=SAMPLE_DTYPE)      # 43 per game always suffice; untouched pages are never made resident
-    n_recs, totals, phases = C.c_uint64(), _lib.Counters(), _lib.PlayPhases()
-    tab = np.ascontiguousarray(reqs, dtype=np.uint64)
-    _lib.check(_lib.lib().c4_play_games_bf16(tab.ctypes.data, n, int(n_mcts_iterations), float(c_exploration), float(c_ply_penalty), C.byref(ns),
-                                             C.byref(opt), counts.ctypes.data, recs.ctypes.data, len(recs), C.byref(n_recs), C.byref(totals), C.byref(phases)))
-    if stats is not None:
-        ph = phases.as_dict()
-        stats.update(totals.as_dict())
-        stats.update(steps=ph["rounds"], n_slots=ph["resident_games"], rows_at_end=ph["rows_at_end"], concurrent_sessions=ph["sessions"], host_loop="native")
-        stats["phases"] = {"setup_s": ph["setup_s"], "start_and_capture_s": 0.0, "steady_s": ph["steady_s"], "tail_s": ph["tail_s"], "drain_s": ph["drain_s"],
-                           "graph_captures": ph["graph_captures"], "recapture_s_inside_steady_and_tail": ph["capture_s"],
-                           "rounds_until_all_started": ph["rounds_until_all_started"], "narrowings": []}
-    return recs[: n_recs.value], counts
-
-
 def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator, device=None,
           resident_games=None, planes_dtype=None, blocks_per_slot=0, stats=None, dirichlet=None, concurrent_sessions=None,
           eval_cache_entries=0, on_device=False, reclaim=None, reclaim_period=0, host_loop=None):
@@ -356,8 +321,10 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
     if host_loop != "python" and not on_device:     # (on_device: the records stay on the GPU for the sample all-gather -- the Python loop's hand-over)
         why = _native_loop_refusal(evaluator, device, planes_dtype, concurrent_sessions)
         if why is None:
-            return _play_native(reqs, n_mcts_iterations, c_exploration, c_ply_penalty, evaluator, resident_games, blocks_per_slot, stats, dirichlet,
-                                concurrent_sessions, eval_cache_entries, reclaim, reclaim_period)
+            from .native import run_native
+            return run_native(reqs, n_mcts_iterations, c_exploration, c_ply_penalty, evaluator, resident_games=resident_games, concurrent_sessions=concurrent_sessions,
+                              blocks_per_slot=blocks_per_slot, reclaim=reclaim, reclaim_period=reclaim_period, dirichlet=dirichlet,
+                              eval_cache_entries=eval_cache_entries, stats=stats)
         if host_loop == "native":
             raise TypeError(f"host_loop='native': {why}")
     multi = evaluator is not None and isinstance(evaluator, dict)

@@ -42,28 +42,19 @@ def network_struct(net) -> _lib.NetworkBf16:
     return s
 
 
-def play_games_native(reqs: Sequence, max_nn_batch_size: int, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float, net, *,
-                      resident_games: Optional[int] = None, concurrent_sessions: Optional[int] = None, steps_per_graph: int = 0,
-                      tail_steps_per_graph: int = 0, blocks_per_slot: int = 0, reclaim: Optional[bool] = None, reclaim_period: int = 0,
-                      dirichlet: Optional[tuple] = None, eval_cache_entries: int = 0, stats: Optional[dict] = None) -> PlayGamesResult:
-    """The reference's six arguments (max_nn_batch_size has no meaning in device mode: every resident game's leaf is a row) with
-    `net` in place of the callback, and `play_games`' keywords plus the graph lengths; the whole job runs inside ONE library call.
-    (`play_games(evaluator=net)` takes this path by itself for an unmodified InferenceNet; this entry point insists on it.)"""
-    from .api import _ids_of
+def run_native(ids: np.ndarray, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float, net, *, resident_games=None,
+               concurrent_sessions=None, steps_per_graph: int = 0, tail_steps_per_graph: int = 0, blocks_per_slot: int = 0, reclaim=None,
+               reclaim_period: int = 0, dirichlet=None, eval_cache_entries: int = 0, stats: Optional[dict] = None):
+    """One `c4_play_games_bf16` call for the requests `ids` (uint64[n, 3]): (records, counts) in request order; `stats` receives the
+    sessions' counters and where the call's wall time went, under the keys the Python loop uses (c4a0_amd/api.py _play)."""
+    import torch
+
     from .session import SAMPLE_DTYPE
 
-    ids = _ids_of(reqs)
-    if bool((ids[:, 1] != ids[:, 2]).any()):
-        raise TypeError("games between different models need play_games(evaluator={model_id: evaluator, ...})")
-    if int(max_nn_batch_size) < 1 or int(n_mcts_iterations) < 0:
-        raise ValueError("max_nn_batch_size must be >= 1 and n_mcts_iterations >= 0")
     n = len(ids)
-    if n == 0:
-        return PlayGamesResult([])
-    L = _lib.lib()
     ns = network_struct(net)
     opt = _lib.PlayOptions()
-    opt.device = net.device.index if net.device.index is not None else 0
+    opt.device = net.device.index if net.device.index is not None else torch.cuda.current_device()
     opt.resident_games, opt.concurrent_sessions = int(resident_games or 0), int(concurrent_sessions or 0)
     opt.steps_per_graph, opt.tail_steps_per_graph = int(steps_per_graph), int(tail_steps_per_graph)
     opt.blocks_per_slot, opt.reclaim_period = int(blocks_per_slot), int(reclaim_period)
@@ -74,14 +65,32 @@ def play_games_native(reqs: Sequence, max_nn_batch_size: int, n_mcts_iterations:
     counts = np.empty(n, dtype=np.uint32)
     recs = np.empty(n * _lib.MAX_SAMPLES_PER_GAME, dtype=SAMPLE_DTYPE)      # 43 per game always suffice; untouched pages are never made resident
     n_recs, totals, phases = C.c_uint64(), _lib.Counters(), _lib.PlayPhases()
-    reqs_tab = np.ascontiguousarray(ids)
-    _lib.check(L.c4_play_games_bf16(reqs_tab.ctypes.data, n, int(n_mcts_iterations), float(c_exploration), float(c_ply_penalty), C.byref(ns),
-                                    C.byref(opt), counts.ctypes.data, recs.ctypes.data, len(recs), C.byref(n_recs), C.byref(totals), C.byref(phases)))
+    tab = np.ascontiguousarray(ids, dtype=np.uint64)
+    _lib.check(_lib.lib().c4_play_games_bf16(tab.ctypes.data, n, int(n_mcts_iterations), float(c_exploration), float(c_ply_penalty), C.byref(ns),
+                                             C.byref(opt), counts.ctypes.data, recs.ctypes.data, len(recs), C.byref(n_recs), C.byref(totals), C.byref(phases)))
     if stats is not None:
-        stats.update(totals.as_dict())
         ph = phases.as_dict()
+        stats.update(totals.as_dict())
         stats.update(steps=ph["rounds"], n_slots=ph["resident_games"], rows_at_end=ph["rows_at_end"], concurrent_sessions=ph["sessions"], host_loop="native")
         stats["phases"] = {"setup_s": ph["setup_s"], "start_and_capture_s": 0.0, "steady_s": ph["steady_s"], "tail_s": ph["tail_s"], "drain_s": ph["drain_s"],
                            "graph_captures": ph["graph_captures"], "recapture_s_inside_steady_and_tail": ph["capture_s"],
                            "rounds_until_all_started": ph["rounds_until_all_started"], "narrowings": []}
-    return results_from_records(ids, recs[: n_recs.value], counts)
+    return recs[: n_recs.value], counts
+
+
+def play_games_native(reqs: Sequence, max_nn_batch_size: int, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float, net, *,
+                      stats: Optional[dict] = None, **options) -> PlayGamesResult:
+    """The reference's six arguments (max_nn_batch_size has no meaning in device mode: every resident game's leaf is a row) with
+    `net` in place of the callback, and `run_native`'s keywords (`play_games`' plus the graph lengths); the whole job runs inside ONE
+    library call.  (`play_games(evaluator=net)` takes this path by itself for an unmodified InferenceNet; this entry point insists.)"""
+    from .api import _ids_of
+
+    ids = _ids_of(reqs)
+    if bool((ids[:, 1] != ids[:, 2]).any()):
+        raise TypeError("games between different models need play_games(evaluator={model_id: evaluator, ...})")
+    if int(max_nn_batch_size) < 1 or int(n_mcts_iterations) < 0:
+        raise ValueError("max_nn_batch_size must be >= 1 and n_mcts_iterations >= 0")
+    if len(ids) == 0:
+        return PlayGamesResult([])
+    recs, counts = run_native(ids, n_mcts_iterations, c_exploration, c_ply_penalty, net, stats=stats, **options)
+    return results_from_records(ids, recs, counts)
