@@ -318,13 +318,13 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
         reqs = _ids_of(reqs)
     if host_loop not in (None, "native", "python"):
         raise ValueError('host_loop must be None, "native" or "python"')
-    if host_loop != "python" and not on_device:     # (on_device: the records stay on the GPU for the sample all-gather -- the Python loop's hand-over)
+    if host_loop != "python":
         why = _native_loop_refusal(evaluator, device, planes_dtype, concurrent_sessions)
         if why is None:
             from .native import run_native
             return run_native(reqs, n_mcts_iterations, c_exploration, c_ply_penalty, evaluator, resident_games=resident_games, concurrent_sessions=concurrent_sessions,
                               blocks_per_slot=blocks_per_slot, reclaim=reclaim, reclaim_period=reclaim_period, dirichlet=dirichlet,
-                              eval_cache_entries=eval_cache_entries, stats=stats)
+                              eval_cache_entries=eval_cache_entries, stats=stats, on_device=on_device)
         if host_loop == "native":
             raise TypeError(f"host_loop='native': {why}")
     multi = evaluator is not None and isinstance(evaluator, dict)

@@ -371,7 +371,7 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
     hipLaunchKernelGGL(k_merge_samples, dim3((unsigned)n_games), dim3(64), 0, s0, margs, (const unsigned long long*)j.offsets_dev, n_games,
                        (c4_sample_rec*)j.merged_dev);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(records_host, j.merged_dev, total * sizeof(c4_sample_rec), hipMemcpyDeviceToHost, s0));
+    HIP_OK(hipMemcpyAsync(records_host, j.merged_dev, total * sizeof(c4_sample_rec), hipMemcpyDefault, s0));   // host memory, or a device buffer (the sample all-gather's input)
     HIP_OK(hipStreamSynchronize(s0));
   }
   const double t_end = now_s();

@@ -44,9 +44,10 @@ def network_struct(net) -> _lib.NetworkBf16:
 
 def run_native(ids: np.ndarray, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float, net, *, resident_games=None,
                concurrent_sessions=None, steps_per_graph: int = 0, tail_steps_per_graph: int = 0, blocks_per_slot: int = 0, reclaim=None,
-               reclaim_period: int = 0, dirichlet=None, eval_cache_entries: int = 0, stats: Optional[dict] = None):
+               reclaim_period: int = 0, dirichlet=None, eval_cache_entries: int = 0, stats: Optional[dict] = None, on_device: bool = False):
     """One `c4_play_games_bf16` call for the requests `ids` (uint64[n, 3]): (records, counts) in request order; `stats` receives the
-    sessions' counters and where the call's wall time went, under the keys the Python loop uses (c4a0_amd/api.py _play)."""
+    sessions' counters and where the call's wall time went, under the keys the Python loop uses (c4a0_amd/api.py _play).
+    on_device=True: the records stay on the GPU, a uint8[n, 64] tensor (what the multi-GPU path all-gathers)."""
     import torch
 
     from .session import SAMPLE_DTYPE
@@ -63,11 +64,17 @@ def run_native(ids: np.ndarray, n_mcts_iterations: int, c_exploration: float, c_
         opt.dirichlet_alpha, opt.dirichlet_epsilon = float(dirichlet[0]), float(dirichlet[1])
     opt.eval_cache_entries = int(eval_cache_entries)
     counts = np.empty(n, dtype=np.uint32)
-    recs = np.empty(n * _lib.MAX_SAMPLES_PER_GAME, dtype=SAMPLE_DTYPE)      # 43 per game always suffice; untouched pages are never made resident
+    cap = n * _lib.MAX_SAMPLES_PER_GAME                                      # 43 per game always suffice
+    if on_device:
+        recs = torch.empty((cap, 64), dtype=torch.uint8, device=net.device)
+        recs_ptr = recs.data_ptr()
+    else:
+        recs = np.empty(cap, dtype=SAMPLE_DTYPE)                             # (untouched pages are never made resident)
+        recs_ptr = recs.ctypes.data
     n_recs, totals, phases = C.c_uint64(), _lib.Counters(), _lib.PlayPhases()
     tab = np.ascontiguousarray(ids, dtype=np.uint64)
     _lib.check(_lib.lib().c4_play_games_bf16(tab.ctypes.data, n, int(n_mcts_iterations), float(c_exploration), float(c_ply_penalty), C.byref(ns),
-                                             C.byref(opt), counts.ctypes.data, recs.ctypes.data, len(recs), C.byref(n_recs), C.byref(totals), C.byref(phases)))
+                                             C.byref(opt), counts.ctypes.data, recs_ptr, cap, C.byref(n_recs), C.byref(totals), C.byref(phases)))
     if stats is not None:
         ph = phases.as_dict()
         stats.update(totals.as_dict())

@@ -310,8 +310,9 @@ typedef struct {
 } c4_play_phases;
 
 /* Plays every game of reqs[0 .. n_games) to the end (self_play.rs:39-129 with the arguments of self_play.rs:39-46) and returns the
- * samples in REQUEST order: counts_host[g] = samples of game g (<= 43), records_host = their records back to back (capacity
- * records_cap records: 43 * n_games always suffice; a smaller buffer that turns out too small -> C4_ERR_BAD_ARG with the number
+ * samples in REQUEST order: counts_host[g] = samples of game g (<= 43), records_host = their records back to back -- host memory, or
+ * DEVICE memory of options->device when the records are to stay on the GPU (one rank's input to the RCCL all-gather of samples) --
+ * (capacity records_cap records: 43 * n_games always suffice; a smaller buffer that turns out too small -> C4_ERR_BAD_ARG with the number
  * needed in *n_records).  totals (may be NULL) = the sessions' counters summed; phases may be NULL.  Synchronous; the records are the
  * same bytes whatever resident_games / concurrent_sessions / graph lengths are chosen (the evaluator is a function of the position,
  * a game's samples do not depend on the slot or session that plays it).  A device-side error (C4_ERR_NAN_IN_TREE, ...) is returned

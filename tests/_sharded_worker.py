@@ -75,7 +75,8 @@ def main():
         res = play_games_sharded(reqs, 64, n_iter, 6.6, 0.01, evaluator=hash_eval_torch, device=device,
                                  resident_games=8, stats=stats)
     with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
-        pickle.dump({"cbor": res.to_cbor(), "allgather": stats["sample_allgather"], "games_done": stats.get("games_done"), **extra}, f)
+        pickle.dump({"cbor": res.to_cbor(), "allgather": stats["sample_allgather"], "games_done": stats.get("games_done"),
+                     "host_loop": stats.get("host_loop"), **extra}, f)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -50,6 +50,8 @@ def test_records_do_not_depend_on_layout_or_mode():
         "resident 1024, two sessions": dict(evaluator=net, resident_games=1024, concurrent_sessions=2),
         "resident 300 (odd batch shape)": dict(evaluator=net, resident_games=300),
         "evaluation cache on": dict(evaluator=net, resident_games=4096, eval_cache_entries=1 << 20),
+        "the Python host loop, two sessions": dict(evaluator=net, resident_games=4096, concurrent_sessions=2, host_loop="python"),
+        "the Python host loop, one session, cache": dict(evaluator=net, resident_games=1024, concurrent_sessions=1, eval_cache_entries=1 << 20, host_loop="python"),
     }
     for name, kw in variants.items():
         assert _records(**kw) == ref, name
@@ -63,11 +65,12 @@ def test_step_shape_is_a_scheduling_knob(monkeypatch):
 
     net = _net()
     monkeypatch.setattr(S, "PAIRED_STEP_GAMES_PER_WAVEFRONT", 4)
-    four = _records(evaluator=net, resident_games=700, concurrent_sessions=2, n=1500)
+    four = _records(evaluator=net, resident_games=700, concurrent_sessions=2, n=1500, host_loop="python")   # (the knob lives in the Python loop; the library's loop asks for 4)
     monkeypatch.setattr(S, "PAIRED_STEP_GAMES_PER_WAVEFRONT", 8)
-    eight = _records(evaluator=net, resident_games=700, concurrent_sessions=2, n=1500)
-    alone = _records(evaluator=net, resident_games=700, concurrent_sessions=1, n=1500)
-    assert four == eight == alone
+    eight = _records(evaluator=net, resident_games=700, concurrent_sessions=2, n=1500, host_loop="python")
+    alone = _records(evaluator=net, resident_games=700, concurrent_sessions=1, n=1500, host_loop="python")
+    native = _records(evaluator=net, resident_games=700, concurrent_sessions=2, n=1500)
+    assert four == eight == alone == native
     s = S.DeviceSession(8, 4, 6.6, 0.01, device=torch.device("cuda:0"))
     with pytest.raises(C4Error):
         s.set_step_shape(5)

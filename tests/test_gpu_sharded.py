@@ -219,5 +219,6 @@ def test_rccl_live_during_graph_capture_collective_before_play_and_two_calls(tmp
     assert p.wait(timeout=600) == 0
     got = pickle.load(open(tmp_path / "rank0.pkl", "rb"))
     assert got["allgather"]["backend"] == "nccl" and got["collectives_before_play"] >= 2
+    assert got["host_loop"] == "native"      # the rank's rounds ran inside c4_play_games_bf16 (its graph captured with RCCL's watchdog thread alive), records left on the device
     assert got["cbor"] == single.to_cbor(), "first call (right after a broadcast + barrier) differs"
     assert got["cbor_second_call"] == single.to_cbor(), "second call in the same process differs"
