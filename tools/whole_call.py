@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--pickle", action="store_true")
     ap.add_argument("--sessions", type=int, default=0)
+    ap.add_argument("--host-loop", default=None, choices=["native", "python"], help="default: play_games' own choice (the library's loop for an InferenceNet)")
+    ap.add_argument("--check-python-loop", action="store_true", help="play the job once more with host_loop='python' and compare the records")
     a = ap.parse_args()
     import c4a0_amd
     from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
@@ -38,9 +40,10 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             res = c4a0_amd.play_games(reqs, 2000, a.n_mcts, 6.6, 0.01, evaluator=net, stats=st, resident_games=res_games or None,
-                                      concurrent_sessions=a.sessions or None)
+                                      concurrent_sessions=a.sessions or None, host_loop=a.host_loop)
             dt = time.perf_counter() - t0
-            out = {"n_games": a.n_games, "resident_games": res_games, "rep": rep, "seconds": round(dt, 4), "games_per_s": round(a.n_games / dt, 1),
+            out = {"n_games": a.n_games, "resident_games": res_games, "rep": rep, "host_loop": st.get("host_loop"), "sessions": st.get("concurrent_sessions"),
+                   "seconds": round(dt, 4), "games_per_s": round(a.n_games / dt, 1),
                    "steps": st["steps"], "sims": st["sims"], "n_slots": st["n_slots"],
                    "phases": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st["phases"].items()}}
             if a.pickle:
@@ -51,6 +54,13 @@ def main():
                 pickle.loads(blob)
                 out["pickle_loads_s"] = round(time.perf_counter() - t0, 4)
                 out["pickle_bytes"] = len(blob)
+            if a.check_python_loop and rep == 0:
+                st2 = {}
+                t0 = time.perf_counter()
+                res2 = c4a0_amd.play_games(reqs, 2000, a.n_mcts, 6.6, 0.01, evaluator=net, stats=st2, resident_games=res_games or None,
+                                           concurrent_sessions=a.sessions or None, host_loop="python")
+                out["python_loop_seconds"] = round(time.perf_counter() - t0, 4)
+                out["python_loop_records_identical"] = bool(res2.to_records()[0].tobytes() == res.to_records()[0].tobytes())
             print(json.dumps(out), flush=True)
 
 
