@@ -339,7 +339,10 @@ def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penal
     # 2 048 rows a single chain's round is shorter than two paired chains' (57 against 65 us at 1 024 games, profiles/r06_whole_call.txt
     # (d)), which outweighs the full-width rounds a pair plays faster (104 against 120 us at 4 096): 4 096 games on 4 096 slots take
     # 0.280 s with one session, 0.297 with two (40 960 games on 4 096 slots: 1.77 against 1.62 -- there the pair wins).
-    parts = int(concurrent_sessions) if concurrent_sessions else (2 if graph_safe and n_slots >= 2048 and len(reqs) > n_slots else 1)
+    # (That is the 32-channel network; with the 64-channel one, five times the arithmetic per row, the pair still wins or ties for one
+    # generation: 8 192 games at n = 200 in 2.79 against 2.89 s, 4 096 at n = 800 in 6.20 against 6.23.)
+    one_generation = len(reqs) <= n_slots and getattr(evaluator, "channels", 32) <= 32
+    parts = int(concurrent_sessions) if concurrent_sessions else (2 if graph_safe and n_slots >= 2048 and not one_generation else 1)
     if parts > 1 and not graph_safe:
         raise TypeError("concurrent_sessions > 1 needs a graph-safe device evaluator (c4a0_amd.nn.InferenceNet)")
     parts = max(1, min(parts, n_slots))

@@ -208,7 +208,9 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
   resident = std::min<uint64_t>(resident, n_games);
   // two paired sessions from 2 048 resident games -- unless the job is one generation (nothing is ever refilled: it is all tail, and
   // below 2 048 rows one chain's round is shorter than two paired chains'; c4a0_amd/api.py _play has the measurements)
-  uint32_t n_parts = opt.concurrent_sessions ? opt.concurrent_sessions : ((resident >= 2048 && n_games > resident) ? 2u : 1u);
+  // (measured with the 32-channel network; the 64-channel one, five times the arithmetic per row, keeps the pair)
+  const bool one_generation = n_games <= resident && net->channels <= 32;
+  uint32_t n_parts = opt.concurrent_sessions ? opt.concurrent_sessions : ((resident >= 2048 && !one_generation) ? 2u : 1u);
   if (n_parts > 2) return fail(C4_ERR_BAD_ARG, "c4_play_games_bf16: one session, or two paired ones");
   n_parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_parts, resident));
   const bool extensions = opt.dirichlet_epsilon > 0.0f || opt.eval_cache_entries != 0;
