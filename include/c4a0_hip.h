@@ -283,7 +283,7 @@ typedef struct {
 typedef struct {
   int32_t device;                /* HIP device ordinal */
   uint32_t resident_games;       /* games advanced in lock-step; 0 = by job size: 4 096 / 8 192 / 16 384 (c4a0_amd/api.py default_resident_games) */
-  uint32_t concurrent_sessions;  /* 0 = two paired sessions from 2 048 resident games when slots are refilled (more games than slots), else one; 1 or 2 to force */
+  uint32_t concurrent_sessions;  /* 0 = two paired sessions from 2 048 resident games -- except one generation (no more games than slots) of a 32-channel network --, else one; 1 or 2 to force */
   uint32_t steps_per_graph;      /* rounds per HIP-graph replay while slots are refilled; 0 = by job length (64 / 32 / 8) */
   uint32_t tail_steps_per_graph; /* ... from the first narrowing of the tail on; 0 = 16 (8 for short jobs) */
   uint32_t blocks_per_slot;      /* c4_config.blocks_per_slot */
