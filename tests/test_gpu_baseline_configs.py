@@ -117,7 +117,7 @@ def _keys_to_positions(keys):
     return mask, value
 
 
-def _run_logging_every_row(net, ids, n_slots, n_iter):
+def _run_logging_every_row(net, ids, n_slots, n_iter, dirichlet=None):
     """One eager session; at EVERY step the key of every slot's leaf and the evaluator's answer for it are logged on the device.
     Returns (records, counts, counters, table) with table = (mask, value, out[n, 9]) sorted by (mask, value): what the evaluator
     said for every distinct position it was shown during the whole job -- after checking that it said the SAME bits every time it
@@ -129,6 +129,8 @@ def _run_logging_every_row(net, ids, n_slots, n_iter):
     dev = torch.device("cuda:0")
     s = DeviceSession(n_slots, n_iter, 6.6, 0.01, device=dev, planes_dtype=torch.bfloat16)
     s.set_games([(g, 0, 0) for g in ids])
+    if dirichlet is not None:
+        s.set_dirichlet(*dirichlet)
     log_k, log_o = [], []
 
     def log(_step):
