@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -244,6 +245,19 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
     C4_TRY(c4_session_set_games(part.s, mine.data(), part.n_games, nullptr, nullptr));
     if (opt.dirichlet_epsilon > 0.0f) C4_TRY(c4_session_set_dirichlet(part.s, opt.dirichlet_alpha, opt.dirichlet_epsilon));
     if (opt.eval_cache_entries) C4_TRY(c4_session_set_eval_cache(part.s, std::max<uint64_t>(1024, opt.eval_cache_entries / n_parts), 0));
+#ifdef C4_DIAG_VARIANTS   // diagnostic build only (build.py --diag): the chip PARTITIONED between the two sessions by CU masks (measured, not adopted)
+    static const int cu_mask_mode = [] { const char* e = getenv("C4_PAIR_CU_MASK"); return e ? atoi(e) : 0; }();
+    if (cu_mask_mode && n_parts == 2) {
+      // the queue's CU mask enumerates compute units round-robin over the 8 XCDs (bit i: XCD i % 8, CU i / 8 of it)
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t cu = 0; cu < 256; cu++) {
+        const bool mine = cu_mask_mode == 1 ? ((cu / 8) < 16) == (p == 0)      // 1: sixteen CUs of EVERY XCD per session
+                                            : ((cu % 8) < 4) == (p == 0);      // 2: four whole XCDs (and their L2s) per session
+        if (mine) mask[cu / 32] |= 1u << (cu % 32);
+      }
+      HIP_OK(hipExtStreamCreateWithCUMask(&part.stream, 8, mask));
+    } else
+#endif
     HIP_OK(hipStreamCreateWithFlags(&part.stream, hipStreamNonBlocking));
     const size_t rows = part.slots;
     HIP_OK(hipMalloc(&part.planes, rows * C4_PLANES_LEN * 2));
@@ -282,6 +296,17 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
   uint64_t steps = 0, steps_all_started = 0, since_check = 0, launched = 0;
   hipStream_t s0 = j.parts[0].stream;
   for (;;) {
+#ifdef C4_DIAG_VARIANTS   // eager launches instead of the graph (a graph's forked branch runs on an internal stream: no CU mask there)
+    static const int eager = [] { const char* e = getenv("C4_PAIR_EAGER"); return e ? atoi(e) : 0; }();
+    if (eager) {
+      for (uint32_t r = 0; r < per_graph; r++)
+        for (Part& p : j.parts) C4_TRY(launch_round(p, *net, j.parts.size() == 1, fused, nullptr, nullptr));
+      if (j.parts.size() == 2) {    // the replay's join: the event ring lives on s0
+        HIP_OK(hipEventRecord(j.ev_join, j.parts[1].stream));
+        HIP_OK(hipStreamWaitEvent(s0, j.ev_join, 0));
+      }
+    } else
+#endif
     HIP_OK(hipGraphLaunch(j.exec, s0));
     HIP_OK(hipEventRecord(j.ring[launched & 3], s0));
     launched++;
