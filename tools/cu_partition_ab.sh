@@ -1,3 +1,5 @@
+# The chip partitioned between the two sessions by queue CU masks, in the library's host loop (diagnostic build) -> profiles/r06_cu_partition.txt
+python c4a0_amd/csrc/build.py --diag > /dev/null
 mkdir -p gpurun_out/r6u; : > gpurun_out/r6u/cu_mask.txt
 export C4A0_HIP_LIB=libc4a0_hip_diag.so
 run() { echo "== $1" >> gpurun_out/r6u/cu_mask.txt; env $2 timeout 200 python tools/whole_call.py 40960 4096 --reps 2 --host-loop native 2>>gpurun_out/r6u/err.txt | python -c "
