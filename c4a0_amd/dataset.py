@@ -44,3 +44,28 @@ def training_tensors(session, augment_flip_h: bool = True):
         return out
     mirrored = records_to_tensors(recs, flip_h=True)
     return tuple(torch.cat([a, b], dim=0) for a, b in zip(out, mirrored))
+
+
+def split_train_test_tensors(result, train_frac: float, seed: int, device=None, augment_flip_h: bool = True):
+    """`games.split_train_test(train_frac, seed)` followed by `SampleDataModule(train, test, ...)` (reference
+    src/c4a0/training.py:207 and 317-333) without a Python object per sample: the SAME partition (whole games to one side, rand's
+    shuffle on `seed`, `PlayGamesResult.split_train_test`) and the same order of samples, as two tuples of tensors on `device` --
+    (pos float32[N,2,6,7], policy float32[N,7], q_penalty float32[N], q_no_penalty float32[N]) for training and for validation --
+    each followed, like `SampleDataModule`, by the mirror images of all its samples (`Sample.flip_h`)."""
+    import numpy as np
+
+    from .results import split_record_indices
+
+    _ids, recs, counts = result._tables()
+    idx, cut = split_record_indices(counts, train_frac, seed)
+    rows = torch.from_numpy(np.ascontiguousarray(recs[idx]).view(np.uint8).reshape(-1, 64))
+    if device is not None:
+        rows = rows.to(device)
+    out = []
+    for part in (rows[:cut], rows[cut:]):
+        t = records_to_tensors(part)
+        if augment_flip_h:
+            m = records_to_tensors(part, flip_h=True)
+            t = tuple(torch.cat([a, b], dim=0) for a, b in zip(t, m))
+        out.append(t)
+    return out[0], out[1]

@@ -463,29 +463,13 @@ class PlayGamesResult:
     # gets the partition it would get from c4a0_rust.
     def split_train_test(self, train_frac: float, seed: int) -> Tuple[List[Sample], List[Sample]]:
         order = shuffled_game_order(len(self), seed)
-        # (len as f32 * train_frac).round(): f32 product, then Rust's f32::round = half AWAY from zero
-        # (np.round is half-to-even: 5 games at 0.5 must give 3, not 2)
-        # ... and Rust's `as usize` saturates: NaN -> 0, negative -> 0, +inf / too large -> usize::MAX (then the
-        # slice bound is clamped to len here, where the reference would panic on an out-of-range split)
-        n_games = len(order)
-        with np.errstate(over="ignore", invalid="ignore"):
-            prod = float(np.float32(n_games) * np.float32(train_frac))
-        if math.isnan(prod) or prod <= 0.0:
-            n_train = 0
-        elif math.isinf(prod):
-            n_train = n_games
-        else:
-            n_train = min(n_games, int(math.floor(prod + 0.5)))
+        n_train = n_train_games(len(order), train_frac)
         if self._lazy is None:
             results = [self._results[i] for i in order.tolist()]
             return [s for r in results[:n_train] for s in r.samples], [s for r in results[n_train:] for s in r.samples]
         _ids, recs, counts = self._lazy                   # `self` stays in record form (and is not mutated: pybridge_test.py:22-39)
-        c64 = counts.astype(np.int64)
-        starts = np.cumsum(c64) - c64
-        oc = c64[order]
-        idx = np.repeat(starts[order] - (np.cumsum(oc) - oc), oc) + np.arange(int(oc.sum()), dtype=np.int64)
+        idx, cut = split_record_indices(counts, train_frac, seed)
         samples = Sample._bulk(recs[idx])
-        cut = int(oc[:n_train].sum())
         return samples[:cut], samples[cut:]
 
     def score_policies(self, solver_path: str, solver_book_path: str, solution_cache_path: str) -> float:
@@ -506,6 +490,31 @@ class PlayGamesResult:
         if not (np.array_equal(ia, ib) and np.array_equal(ca, cb) and np.array_equal(ra["mask"], rb["mask"]) and np.array_equal(ra["value"], rb["value"])):
             return False
         return all(np.ascontiguousarray(ra[f]).tobytes() == np.ascontiguousarray(rb[f]).tobytes() for f in ("policy", "q_penalty", "q_no_penalty"))   # bit for bit, as Sample.__eq__
+
+
+def n_train_games(n_games: int, train_frac: float) -> int:
+    """pybridge.rs:113: `(results.len() as f32 * train_frac).round() as usize` -- the f32 product, Rust's f32::round (halves AWAY from
+    zero: 5 games at 0.5 give 3; np.round is half-to-even) and the saturating `as usize` (NaN -> 0, negative -> 0, +inf / too large ->
+    usize::MAX, then clamped to the number of games here, where the reference would panic on an out-of-range split)."""
+    with np.errstate(over="ignore", invalid="ignore"):
+        prod = float(np.float32(n_games) * np.float32(train_frac))
+    if math.isnan(prod) or prod <= 0.0:
+        return 0
+    if math.isinf(prod):
+        return n_games
+    return min(n_games, int(math.floor(prod + 0.5)))
+
+
+def split_record_indices(counts: np.ndarray, train_frac: float, seed: int) -> Tuple[np.ndarray, int]:
+    """(idx, cut): records[idx[:cut]] are the training samples and records[idx[cut:]] the test samples of split_train_test, in its
+    order (games in rand's shuffled order, whole games on one side, a game's samples in their own order)."""
+    order = shuffled_game_order(len(counts), seed)
+    n_train = n_train_games(len(order), train_frac)
+    c64 = np.asarray(counts).astype(np.int64)
+    starts = np.cumsum(c64) - c64
+    oc = c64[order]
+    idx = np.repeat(starts[order] - (np.cumsum(oc) - oc), oc) + np.arange(int(oc.sum()), dtype=np.int64)
+    return idx, int(oc[:n_train].sum())
 
 
 def shuffled_game_order(n_games: int, seed: int) -> np.ndarray:

@@ -526,3 +526,37 @@ def test_ctypes_structures_match_the_headers_layout_as_gcc_sees_it(tmp_path):
         f = line.split()
         assert f[0] == cname and int(f[1]) == C.sizeof(cls), (cname, f[1], C.sizeof(cls))
         assert [int(x) for x in f[2:]] == [getattr(cls, n).offset for n, _t in cls._fields_], cname
+
+
+def test_split_train_test_tensors_equal_the_per_sample_path():
+    """c4a0_amd.dataset.split_train_test_tensors = what the reference builds sample by sample (training.py:207 `split_train_test`, then
+    `SampleDataModule`: every sample AND its `flip_h()` through `to_numpy`, training.py:317-333) as whole tensors: same partition, same
+    order, same numbers."""
+    import torch
+    from c4a0_amd.dataset import split_train_test_tensors
+    from c4a0_amd.results import results_from_records
+    from c4a0_amd.session import SAMPLE_DTYPE
+
+    rng = np.random.default_rng(11)
+    counts = rng.integers(1, 6, 23).astype(np.uint32)
+    n = int(counts.sum())
+    recs = np.zeros(n, dtype=SAMPLE_DTYPE)
+    recs["mask"] = rng.integers(0, 1 << 42, n, dtype=np.uint64)
+    recs["value"] = recs["mask"] & rng.integers(0, 1 << 42, n, dtype=np.uint64)
+    recs["policy"] = rng.random((n, 7), dtype=np.float32)
+    recs["q_penalty"] = rng.random(n, dtype=np.float32) * 2 - 1
+    recs["q_no_penalty"] = np.sign(recs["q_penalty"])
+    ids = np.stack([np.arange(23, dtype=np.uint64)] * 3, 1)
+    res = results_from_records(ids, recs, counts)
+    for frac, seed in ((0.8, 1337), (0.5, 0), (1.0, 3), (0.0, 3)):
+        train, test = res.split_train_test(frac, seed)
+        got = split_train_test_tensors(res, frac, seed, device="cpu")
+        for samples, tensors in ((train, got[0]), (test, got[1])):
+            samples = samples + [s.flip_h() for s in samples]          # SampleDataModule.__init__
+            assert tensors[0].shape[0] == len(samples)
+            if not samples:
+                continue
+            want = [np.stack(x) for x in zip(*[s.to_numpy() for s in samples])]
+            for t, w in zip(tensors, want):
+                assert t.dtype == torch.float32 and np.array_equal(t.numpy(), w)
+    assert res._lazy is not None
