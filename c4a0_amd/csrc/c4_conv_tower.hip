@@ -810,14 +810,22 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   // config (what a workgroup owns, never a board's arithmetic): 0 = by size (below), 1 = 16 boards / 8 wavefronts,
   // 2 = 8 boards / 8 wavefronts, 3 = 16 boards / 12 wavefronts (27.3 vs 28.0 us alone at 2 048 boards, no difference
   // in the bench).  64 channels: 2 / 3 / 4 below (1 = the default).
-  if (config > 4 || (channels == 32 && config == 4)) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config must be 0 (automatic) .. 3 (32 channels) / .. 4 (64 channels)");
+  if (config > 5 || (channels == 64 && config > 4)) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config must be 0 (automatic) .. 5 (32 channels) / .. 4 (64 channels)");
   if (channels == 64 && config == 4 && Geo<64, 8>::kLdsBytes + 64 + 4 * RingFeed<64>::kStageSlots * 16 + 2 * (int)n_blocks * 64 * 4 > 160 * 1024)
     return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config 4 (weights through an LDS ring) keeps the layers' biases in LDS behind the ring: at most 23 residual blocks");   // an explicitly asked-for shape is run or refused, never swapped for another
   if (channels == 32 && config == 1) return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32 && config == 2) return launch_tower<32, 8, 512, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32 && config == 3) return launch_tower<32, 16, 768, 1>(p, n_boards, (hipStream_t)stream, device);
+  // round 6, for the narrow launches of a job's tail (a round there is latency, and the tower's nine dependent layers were a third of it):
+  // fewer cell tiles per wavefront and layer -- 4: 4 boards on 12 wavefronts (one tile each), 5: 2 boards on 6 wavefronts (one tile each).
+  // Alone under rocprofv3, 4-block tower (profiles/r06_tower_small.txt): 256 boards 16.8 us (8 boards per workgroup) -> 11.8 -> 9.8;
+  // 512: 16.4 -> 12.4 -> 11.2; 1 024: 17.3 -> 13.2 (two boards per workgroup: 15.3); 2 048: 19.2 against 25.2 (four): the cuts below
+  if (channels == 32 && config == 4) return launch_tower<32, 4, 768, 1>(p, n_boards, (hipStream_t)stream, device);
+  if (channels == 32 && config == 5) return launch_tower<32, 2, 384, 1>(p, n_boards, (hipStream_t)stream, device);
+  if (channels == 32 && n_boards <= 512) return launch_tower<32, 2, 384, 1>(p, n_boards, (hipStream_t)stream, device);
+  if (channels == 32 && n_boards <= 1024) return launch_tower<32, 4, 768, 1>(p, n_boards, (hipStream_t)stream, device);
   if (channels == 32 && n_boards <= 8 * 160)
-    // small launches (up to 1 280 boards): 8 boards per workgroup, three tiles in flight per wave, so
+    // small launches (1 025 .. 1 280 boards; round 6: the still smaller ones above): 8 boards per workgroup, three tiles in flight per wave, so
     // that the launch spreads over twice as many CUs (2 048 boards alone: 31.6 -> 20.5 us).  NOT used for
     // the 2 048-board launches of two concurrent sessions: there the other session fills the rest of
     // the chip and what counts is CU-time per board, which is 30 % higher this way (measured: -1.7 %

@@ -101,7 +101,7 @@ int launch_round(Part& p, const c4_network_bf16& net, bool latency, bool fused, 
   void* st = (void*)p.stream;
   if (wait_first) HIP_OK(hipStreamWaitEvent(p.stream, wait_first, 0));
   C4_TRY(c4_conv_tower_bf16(p.planes, net.tower_w0, net.tower_w, net.tower_bias, rows, net.channels, net.n_blocks, p.feat,
-                            (latency && net.channels == 32 && rows <= 2048) ? 2u : 0u, st));
+                            (latency && net.channels == 32 && rows > 1024 && rows <= 2048) ? 2u : 0u, st));   // (as c4a0_amd/nn.py InferenceNet.tower)
   C4_TRY(c4_linear_bf16(p.feat, net.w1, net.b1, p.h1, rows, 2 * F, F, F, 2 * F, 1, alone_config(rows, 2 * F, F, latency), st));
   if (record_stage) HIP_OK(hipEventRecord(record_stage, p.stream));
   const void *hp = p.h1, *hv = (const char*)p.h1 + (size_t)F * 2;   // column ranges of the merged first layer's output

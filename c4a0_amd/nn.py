@@ -259,8 +259,9 @@ class InferenceNet:
             check(self._L.c4_conv_tower_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(self.tw0.data_ptr()),
                                              C.c_void_p(self.tw.data_ptr()), C.c_void_p(self.tbias.data_ptr()),
                                              g, self.channels, self.n_blocks, C.c_void_p(out.data_ptr()),
-                                             # alone on the device (latency_mode): 8 boards per workgroup up to 2 048 boards
-                                             self.tower_config or (2 if (latency and self.channels == 32 and g <= 2048) else 0),
+                                             # alone on the device (latency_mode): 8 boards per workgroup from 1 025 to 2 048 boards
+                                             # (up to 1 024 boards the automatic choice is already the narrow-launch shape: 2 or 4 boards per workgroup)
+                                             self.tower_config or (2 if (latency and self.channels == 32 and 1024 < g <= 2048) else 0),
                                              C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             return out
         x = planes.to(self.dtype)
