@@ -809,8 +809,8 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
   TowerParams p{(const uint16_t*)planes_dev, (const bf16x8*)w0_dev, (const bf16x8*)w_dev, bias_dev, (uint16_t*)out_dev, n_boards, n_blocks};
   // config (what a workgroup owns, never a board's arithmetic): 0 = by size (below), 1 = 16 boards / 8 wavefronts,
   // 2 = 8 boards / 8 wavefronts, 3 = 16 boards / 12 wavefronts (27.3 vs 28.0 us alone at 2 048 boards, no difference
-  // in the bench).  64 channels: 2 / 3 / 4 below (1 = the default).
-  if (config > 5 || (channels == 64 && config > 4)) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config must be 0 (automatic) .. 5 (32 channels) / .. 4 (64 channels)");
+  // in the bench).  64 channels: 2 .. 6 below (1 = the default shape at any size).
+  if (config > 6 || (channels == 32 && config > 5)) return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config must be 0 (automatic) .. 5 (32 channels) / .. 6 (64 channels)");
   if (channels == 64 && config == 4 && Geo<64, 8>::kLdsBytes + 64 + 4 * RingFeed<64>::kStageSlots * 16 + 2 * (int)n_blocks * 64 * 4 > 160 * 1024)
     return c4host::fail(C4_ERR_BAD_ARG, "c4_conv_tower_bf16: config 4 (weights through an LDS ring) keeps the layers' biases in LDS behind the ring: at most 23 residual blocks");   // an explicitly asked-for shape is run or refused, never swapped for another
   if (channels == 32 && config == 1) return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);
@@ -840,6 +840,11 @@ int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w
 #endif
   if (channels == 32)
     return launch_tower<32, 16, 512, 1>(p, n_boards, (hipStream_t)stream, device);   // 8 waves: two per SIMD
+  // round 6, the narrow launches of a 64-channel job's tail -- 5: 4 boards on 8 wavefronts, 6: 2 boards on 4 wavefronts (pairs split the
+  // output channels as in the default).  Alone under rocprofv3, 8-block tower (profiles/r06_tower_small.txt): 256 boards 80.9 us (8 boards
+  // per workgroup) -> 48.0 -> 36.2; 512: 83.2 -> 51.3 -> 39.4; 768: 86.3 -> 56.2 -> 56.7; 1 024: 87.9 -> 60.1 -> 61.5; 1 280: 92.5 against 100.6 / 92.1
+  if (channels == 64 && (config == 5 || (config == 0 && n_boards > 512 && n_boards <= 1024))) return launch_tower<64, 4, 512, 2, true>(p, n_boards, (hipStream_t)stream, device);
+  if (channels == 64 && (config == 6 || (config == 0 && n_boards <= 512))) return launch_tower<64, 2, 256, 2, true>(p, n_boards, (hipStream_t)stream, device);
   // 64 channels, round 5: FOUR wavefronts, one per SIMD, each with all 64 output channels of two whole boards (no hand-over between
   // layers at all) and a weight ring 6 / 3 k-steps deep in its 512 registers (config 2 / 3)
   if (channels == 64 && config == 2) return launch_tower<64, 8, 256, 1, true, 6>(p, n_boards, (hipStream_t)stream, device);

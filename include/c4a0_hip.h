@@ -418,10 +418,11 @@ int c4_sample_move(const uint64_t* game_id_dev, const uint32_t* n_moves_dev, con
  *   w0_dev / w_dev / bias_dev: MFMA-fragment-ordered weights, see c4a0_amd/nn.py::pack_tower_weights
  *   out_dev    bf16 [n_boards][42][channels]  (cell-major, channels last)
  * channels must be 32 or 64.  config: 0 = the workgroup shape chosen from n_boards (32 channels: 2 boards up to 512 boards, 4 up to
- * 1 024, 8 up to 1 280, else 16); 32 channels: 1 / 2 / 3 = 16 boards, 8 boards, 16 boards on 12 wavefronts, 4 / 5 = 4 boards on 12
+ * 1 024, 8 up to 1 280, else 16; 64 channels: 2 up to 512, 4 up to 1 024, else 8); 32 channels: 1 / 2 / 3 = 16 boards, 8 boards, 16 boards on 12 wavefronts, 4 / 5 = 4 boards on 12
  * wavefronts, 2 boards on 6 (the narrow launches of a job's tail); 64 channels: 2 / 3 = four wavefronts (one per SIMD, whole boards and all 64 output channels each)
  * with a weight ring 6 / 3 k-steps deep instead of the default eight wavefronts in channel-splitting pairs, 4 = the eight wavefronts
- * with the weights fetched once per workgroup into an LDS ring (a workgroup barrier per tap) -- every shape computes the same bits. */
+ * with the weights fetched once per workgroup into an LDS ring (a workgroup barrier per tap), 5 / 6 = 4 boards on eight wavefronts, 2 boards
+ * on four (narrow launches), 1 = the default shape at any size -- every shape computes the same bits. */
 int c4_conv_tower_bf16(const void* planes_dev, const void* w0_dev, const void* w_dev, const float* bias_dev,
                        uint32_t n_boards, uint32_t channels, uint32_t n_blocks, void* out_dev, uint32_t config, void* stream);
 
