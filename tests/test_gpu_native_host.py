@@ -130,3 +130,25 @@ def test_default_shapes_and_errors():
     assert rc == _lib.ERR_BAD_ARG and n.value == counts.sum() > 40 and b"room for 40" in L.c4_last_error_string()
     ns.channels = 48
     assert L.c4_play_games_bf16(reqs.ctypes.data, 40, 8, 6.6, 0.01, C.byref(ns), None, counts.ctypes.data, recs.ctypes.data, 40, C.byref(n), None, None) == _lib.ERR_BAD_ARG
+
+
+def test_repeated_calls_give_back_what_they_took():
+    """A training loop calls play_games once per generation (reference src/c4a0/training.py:176-189), for days: every call builds its
+    sessions, streams, events and graphs and must give all of it back -- free device memory after forty jobs of either shape (one
+    session; a pair with refill, narrowing and re-captures) stays where it was after the first ones, and the bytes stay the same."""
+    import c4a0_amd
+    from c4a0_amd.native import play_games_native
+
+    net = _net(1, 32)
+    shapes = [(300, 10, {}), (1500, 6, {"resident_games": 1024, "concurrent_sessions": 2})]
+    first = {}
+    for rep in range(20):
+        for i, (n_games, n_iter, kw) in enumerate(shapes):
+            reqs = [c4a0_amd.GameMetadata(g, 0, 0) for g in range(n_games)]
+            got = play_games_native(reqs, 4096, n_iter, 6.6, 0.01, net, **kw).to_records()[0].tobytes()
+            assert first.setdefault(i, got) == got
+        if rep == 1:
+            torch.cuda.synchronize()
+            free_then = torch.cuda.mem_get_info()[0]
+    torch.cuda.synchronize()
+    assert free_then - torch.cuda.mem_get_info()[0] < 8 << 20, (free_then, torch.cuda.mem_get_info()[0])
