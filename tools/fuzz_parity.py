@@ -17,6 +17,7 @@ from tests.helpers import hash_eval_np
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20260002)
+rng_net = random.Random((int(sys.argv[2]) if len(sys.argv) > 2 else 20260002) * 7919 + 64)   # network shapes (channels, blocks): their own generator
 t0, n_jobs, n_games_total, n_errs, n_cb_jobs = time.time(), 0, 0, 0, 0
 n_reclaimed_jobs = 0
 n_dirichlet_jobs = 0
@@ -84,9 +85,10 @@ def fused_job():
     from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
     from c4a0_amd.results import GameMetadata, results_from_records
     heads = rng.choice([(2, 2), (4, 2), (1, 1), (3, 1)])
+    heads = heads + (rng_net.choice([32, 32, 64]),)     # (its own generator: the job sequence of a seed stays what it was)
     if heads not in _nets:
         torch.manual_seed(hash(heads) & 0xFFFF)
-        _nets[heads] = InferenceNet(ConnectFourNet(ModelConfig(rng.choice([1, 2]), 32, *heads)), torch.device("cuda:0"), dtype=torch.bfloat16)
+        _nets[heads] = InferenceNet(ConnectFourNet(ModelConfig(rng_net.choice([1, 2]), heads[2], *heads[:2])), torch.device("cuda:0"), dtype=torch.bfloat16)
     net = _nets[heads]
     n_games = rng.choice([1, 5, 16, 17, 40, 130])
     n_slots = rng.choice([1, 7, 8, 15, 16, 17, 31, 33, 100])
@@ -118,10 +120,10 @@ def native_job():
     from c4a0_amd.nn import ConnectFourNet, InferenceNet, ModelConfig
     from c4a0_amd.results import GameMetadata, results_from_records
     heads = rng.choice([(2, 2), (4, 2), (3, 3)])
-    key = ("native",) + heads
+    key = ("native",) + heads + (rng_net.choice([32, 32, 64]),)
     if key not in _nets:
         torch.manual_seed(hash(key) & 0xFFFF)
-        _nets[key] = InferenceNet(ConnectFourNet(ModelConfig(rng.choice([1, 2]), 32, *heads)), torch.device("cuda:0"), dtype=torch.bfloat16)
+        _nets[key] = InferenceNet(ConnectFourNet(ModelConfig(rng_net.choice([1, 2]), key[3], *heads)), torch.device("cuda:0"), dtype=torch.bfloat16)
     net = _nets[key]
     n_games = rng.choice([1, 5, 16, 17, 40, 130, 600])
     n_slots = rng.choice([1, 7, 8, 15, 16, 33, 100, 300])
