@@ -63,8 +63,18 @@ struct Job {
   hipGraphExec_t exec = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stage = nullptr, ring[4] = {nullptr, nullptr, nullptr, nullptr};
   void *merged_dev = nullptr, *offsets_dev = nullptr;
+  // Waits for everything this job has launched: its streams only -- the caller's other streams on the device (a training step, a
+  // copy) are none of this loop's business and are never waited for after set-up.
+  hipError_t sync() {
+    for (Part& p : parts)
+      if (p.stream) {
+        const hipError_t e = hipStreamSynchronize(p.stream);
+        if (e != hipSuccess) return e;
+      }
+    return hipSuccess;
+  }
   ~Job() {
-    (void)hipDeviceSynchronize();
+    if (sync() != hipSuccess) (void)hipDeviceSynchronize();
     if (exec) (void)hipGraphExecDestroy(exec);
     for (Part& p : parts) {
       if (p.s) (void)c4_session_destroy(p.s);
@@ -128,7 +138,7 @@ int capture(Job& j, const c4_network_bf16& net, uint32_t rounds, bool fused) {
   // outside the capture, once at this width: the evaluator on the current leaves (first use of a tile shape opts its kernel in for
   // more than 64 KB of LDS, which is not a stream operation); evaluating the leaves once more changes nothing a game sees
   for (Part& p : j.parts) C4_TRY(launch_round(p, net, latency, fused, nullptr, nullptr, true));
-  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(j.sync());
   HIP_OK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
   int rc = C4_OK;
   hipError_t he = hipSuccess;
@@ -318,7 +328,7 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
       uint32_t err = 0;
       C4_TRY(c4_session_progress(p.s, &p.done, &p.started, &err));
       if (err) {
-        (void)hipDeviceSynchronize();
+        (void)j.sync();
         c4_counters c{};
         (void)c4_session_counters(p.s, &c);
         if (totals) { totals->error = c.error; totals->error_slot = c.error_slot; }
@@ -342,7 +352,7 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
         any = any || wants[k];
       }
       if (any) {
-        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(j.sync());
         bool changed = false;
         for (size_t k = 0; k < j.parts.size(); k++) {
           if (!wants[k]) continue;
@@ -359,7 +369,7 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
       }
     }
   }
-  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(j.sync());
   const double t_drain = now_s();
 
   // ---- counters, then the records: per-game counts to the host, offsets in request order back, one merge kernel, one transfer
