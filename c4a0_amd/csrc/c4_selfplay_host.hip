@@ -301,7 +301,6 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
     return rc;
   };
   C4_TRY(recapture(per_graph));
-  const double t_loop = now_s();
   double t_all_started = 0.0;
   uint64_t steps = 0, steps_all_started = 0, since_check = 0, launched = 0;
   hipStream_t s0 = j.parts[0].stream;
@@ -415,7 +414,7 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
   if (phases) {
     phases->setup_s = t_setup - t0;
     phases->capture_s = capture_s;
-    phases->steady_s = (t_all_started ? t_all_started : t_drain) - t_loop;
+    phases->steady_s = (t_all_started ? t_all_started : t_drain) - t_setup;   // (the first capture included: the phases add up to the call)
     phases->tail_s = t_drain - (t_all_started ? t_all_started : t_drain);
     phases->drain_s = t_end - t_drain;
     phases->rounds = steps;

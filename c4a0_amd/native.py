@@ -79,7 +79,7 @@ def run_native(ids: np.ndarray, n_mcts_iterations: int, c_exploration: float, c_
         ph = phases.as_dict()
         stats.update(totals.as_dict())
         stats.update(steps=ph["rounds"], n_slots=ph["resident_games"], rows_at_end=ph["rows_at_end"], concurrent_sessions=ph["sessions"], host_loop="native")
-        stats["phases"] = {"setup_s": ph["setup_s"], "start_and_capture_s": 0.0, "steady_s": ph["steady_s"], "tail_s": ph["tail_s"], "drain_s": ph["drain_s"],
+        stats["phases"] = {"setup_s": ph["setup_s"], "start_and_capture_s": 0.0, "first_capture_inside": "steady_s", "steady_s": ph["steady_s"], "tail_s": ph["tail_s"], "drain_s": ph["drain_s"],
                            "graph_captures": ph["graph_captures"], "recapture_s_inside_steady_and_tail": ph["capture_s"],
                            "rounds_until_all_started": ph["rounds_until_all_started"], "narrowings": []}
     return recs[: n_recs.value], counts

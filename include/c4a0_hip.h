@@ -294,11 +294,11 @@ typedef struct {
   uint64_t eval_cache_entries;   /* EXTENSION, off at 0: c4_session_set_eval_cache (split over the sessions) */
 } c4_play_options;
 
-/* Where the call's wall time went (seconds) and what it chose. */
+/* Where the call's wall time went (seconds; setup_s + steady_s + tail_s + drain_s = the call) and what it chose. */
 typedef struct {
   double setup_s;                /* sessions, arenas, activation buffers, streams */
   double capture_s;              /* all graph captures (the first one and those after a narrowing: inside steady_s / tail_s too) */
-  double steady_s;               /* from the first replay until every request had been started (all slots busy) */
+  double steady_s;               /* from the end of set-up (the first capture, then the first replay) until every request had been started (all slots busy) */
   double tail_s;                 /* after that, until the last game ended */
   double drain_s;                /* counters, merge, transfer of the records */
   uint64_t rounds;               /* lock-step rounds replayed */

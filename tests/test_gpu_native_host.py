@@ -152,3 +152,24 @@ def test_repeated_calls_give_back_what_they_took():
             free_then = torch.cuda.mem_get_info()[0]
     torch.cuda.synchronize()
     assert free_then - torch.cuda.mem_get_info()[0] < 8 << 20, (free_then, torch.cuda.mem_get_info()[0])
+
+
+def test_the_phases_add_up_to_the_call():
+    """c4_play_phases: set-up + steady + tail + drain is the call's wall time (the first capture counted inside steady_s)."""
+    import time
+
+    import c4a0_amd
+    from c4a0_amd.native import play_games_native
+
+    net = _net(1, 32)
+    reqs = [c4a0_amd.GameMetadata(g, 0, 0) for g in range(3000)]
+    play_games_native(reqs[:64], 4096, 6, 6.6, 0.01, net)
+    st = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    play_games_native(reqs, 4096, 12, 6.6, 0.01, net, stats=st, resident_games=2048)
+    dt = time.perf_counter() - t0
+    ph = st["phases"]
+    total = ph["setup_s"] + ph["steady_s"] + ph["tail_s"] + ph["drain_s"]
+    assert total <= dt and dt - total < 0.05 + 0.1 * dt, (ph, dt)
+    assert ph["graph_captures"] >= 1 and 0 < ph["recapture_s_inside_steady_and_tail"] < total
