@@ -14,6 +14,7 @@ The tree path always runs in the HIP kernels; there is no CPU implementation to 
 """
 from __future__ import annotations
 
+import threading
 import time
 from typing import Callable, Optional, Sequence
 
@@ -306,12 +307,29 @@ def _native_loop_refusal(evaluator, device, planes_dtype, concurrent_sessions) -
     return None
 
 
+# One job at a time per process: a job captures HIP graphs, and a capture does not tolerate what another job's set-up does meanwhile
+# (allocations, transfers on the legacy stream) -- two threads calling play_games at once used to fail with "operation would make the
+# legacy stream depend on a capturing stream".  A job fills the device anyway; the second caller waits.  (Re-entrant: a numpy callback
+# may itself call play_games.)  The library's own loop holds the same kind of lock for hosts that are not Python (c4_selfplay_host.hip).
+_JOB_LOCK = threading.RLock()
+
+
 def _play(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator, device=None,
           resident_games=None, planes_dtype=None, blocks_per_slot=0, stats=None, dirichlet=None, concurrent_sessions=None,
           eval_cache_entries=0, on_device=False, reclaim=None, reclaim_period=0, host_loop=None):
     """Play `reqs` (a uint64[n, 3] table of ids, or GameMetadata-like objects) on ONE device.  Returns (records, counts) in request order; `records` is a numpy
     SAMPLE_DTYPE array, or with on_device=True a uint8[n, 64] tensor that never left the GPU (packed
-    by k_pack_samples: what the sample all-gather of the multi-GPU path sends)."""
+    by k_pack_samples: what the sample all-gather of the multi-GPU path sends).  Jobs of concurrent threads run one after another."""
+    with _JOB_LOCK:
+        return _play_locked(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator, device=device,
+                            resident_games=resident_games, planes_dtype=planes_dtype, blocks_per_slot=blocks_per_slot, stats=stats, dirichlet=dirichlet,
+                            concurrent_sessions=concurrent_sessions, eval_cache_entries=eval_cache_entries, on_device=on_device, reclaim=reclaim,
+                            reclaim_period=reclaim_period, host_loop=host_loop)
+
+
+def _play_locked(reqs, max_nn_batch_size, n_mcts_iterations, c_exploration, c_ply_penalty, py_eval_pos_cb, evaluator, device=None,
+                 resident_games=None, planes_dtype=None, blocks_per_slot=0, stats=None, dirichlet=None, concurrent_sessions=None,
+                 eval_cache_entries=0, on_device=False, reclaim=None, reclaim_period=0, host_loop=None):
     from .session import run_sessions
 
     if not isinstance(reqs, np.ndarray):

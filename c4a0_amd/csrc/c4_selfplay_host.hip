@@ -24,6 +24,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -201,6 +202,11 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
   if (net->channels != 32 && net->channels != 64) return fail(C4_ERR_BAD_ARG, "c4_play_games_bf16: the evaluator's kernels take 32 or 64 channels");
   if (!net->w1 || !net->b1) return fail(C4_ERR_BAD_ARG, "c4_play_games_bf16: both heads need a hidden layer (the merged first layer w1 / b1)");
   if (net->n_policy_hidden > 8 || net->n_value_hidden > 8) return fail(C4_ERR_BAD_ARG, "c4_play_games_bf16: at most 8 further hidden layers per head");
+  // One job at a time: a job captures HIP graphs, and a capture does not tolerate what another job's set-up does meanwhile (allocations,
+  // memsets and transfers on the legacy stream: "operation would make the legacy stream depend on a capturing stream") -- two threads of
+  // a host calling at once used to fail that way.  A job fills the device anyway; the second caller waits here.
+  static std::mutex one_job;
+  std::lock_guard<std::mutex> hold(one_job);
   const double t0 = now_s();
   c4host::DeviceGuard guard(opt.device);
   if (guard.error() != hipSuccess) return fail(C4_ERR_HIP, std::string("c4_play_games_bf16: hipSetDevice: ") + hipGetErrorString(guard.error()));

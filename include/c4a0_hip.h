@@ -316,7 +316,8 @@ typedef struct {
  * needed in *n_records).  totals (may be NULL) = the sessions' counters summed; phases may be NULL.  Synchronous; the records are the
  * same bytes whatever resident_games / concurrent_sessions / graph lengths are chosen (the evaluator is a function of the position,
  * a game's samples do not depend on the slot or session that plays it).  A device-side error (C4_ERR_NAN_IN_TREE, ...) is returned
- * as the status, with the slot in totals->error_slot. */
+ * as the status, with the slot in totals->error_slot.  Thread-safe by exclusion: calls of concurrent threads run one after another
+ * (a job captures HIP graphs, which another job's set-up on the same process would break; a job fills the device anyway). */
 int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games, uint32_t n_mcts_iterations, float c_exploration,
                        float c_ply_penalty, const c4_network_bf16* net, const c4_play_options* options, uint32_t* counts_host,
                        c4_sample_rec* records_host, uint64_t records_cap, uint64_t* n_records, c4_counters* totals,

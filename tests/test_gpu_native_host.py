@@ -173,3 +173,41 @@ def test_the_phases_add_up_to_the_call():
     total = ph["setup_s"] + ph["steady_s"] + ph["tail_s"] + ph["drain_s"]
     assert total <= dt and dt - total < 0.05 + 0.1 * dt, (ph, dt)
     assert ph["graph_captures"] >= 1 and 0 < ph["recapture_s_inside_steady_and_tail"] < total
+
+
+@pytest.mark.parametrize("host_loop", ["native", "python"])
+def test_concurrent_callers_get_their_own_bytes(host_loop):
+    """Four threads call play_games at once (ctypes releases the interpreter lock for the library's loop): a job captures HIP
+    graphs, and another job's set-up in the middle of a capture used to fail it ("operation would make the legacy stream depend
+    on a capturing stream") -- jobs now run one after another, and every caller gets exactly the bytes of a call made alone."""
+    import threading
+
+    import c4a0_amd
+
+    net = _net(1, 32)
+    shapes = [(0, 3000, 10, dict(resident_games=1024, concurrent_sessions=2)), (100000, 500, 20, {}), (200000, 2500, 8, dict(resident_games=2048)), (300000, 64, 30, {})]
+
+    def job(first_id, n_games, n_iter, kw):
+        reqs = [c4a0_amd.GameMetadata(first_id + i, 0, 0) for i in range(n_games)]
+        if host_loop == "native":     # straight into c4_play_games_bf16 (not through play_games' own lock): the library's exclusion is what holds
+            from c4a0_amd.native import play_games_native
+            return play_games_native(reqs, 4096, n_iter, 6.6, 0.01, net, **kw).to_records()[0].tobytes()
+        return c4a0_amd.play_games(reqs, 4096, n_iter, 6.6, 0.01, evaluator=net, host_loop=host_loop, **kw).to_records()[0].tobytes()
+
+    want = [job(*s) for s in shapes]
+    for _ in range(2):
+        got, errs = [None] * len(shapes), []
+
+        def run(i):
+            try:
+                got[i] = job(*shapes[i])
+            except Exception as e:  # noqa: BLE001
+                errs.append((i, repr(e)))
+
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(len(shapes))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errs, errs
+        assert got == want
