@@ -211,3 +211,26 @@ def test_concurrent_callers_get_their_own_bytes(host_loop):
             t.join()
         assert not errs, errs
         assert got == want
+
+
+@pytest.mark.parametrize("sessions", [1, 2])
+def test_a_device_side_panic_ends_the_call_and_poisons_nothing(sessions):
+    """A network that answers NaN (here: a NaN in the value head's output bias) makes the reference panic in UCT (utils.rs:12); the
+    library's loop returns that status from its pinned probes, gives everything back, and the next call plays as if nothing had been."""
+    import c4a0_amd
+    from c4a0_amd._lib import C4Error
+    from c4a0_amd.native import play_games_native
+
+    good, bad = _net(1, 32), _net(1, 32)
+    bad.val_b32.fill_(float("nan"))
+    reqs = [c4a0_amd.GameMetadata(g, 0, 0) for g in range(600)]
+    kw = dict(resident_games=512, concurrent_sessions=sessions)
+    want = play_games_native(reqs, 4096, 8, 6.6, 0.01, good, **kw).to_records()[0].tobytes()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        with pytest.raises(C4Error, match="NAN|nan|NaN"):
+            play_games_native(reqs, 4096, 8, 6.6, 0.01, bad, **kw)
+    torch.cuda.synchronize()
+    assert free_before - torch.cuda.mem_get_info()[0] < 8 << 20
+    assert play_games_native(reqs, 4096, 8, 6.6, 0.01, good, **kw).to_records()[0].tobytes() == want
