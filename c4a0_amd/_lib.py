@@ -11,17 +11,17 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("C4A0_HIP_LIB", "libc4a0_hip.so"))  # C4A0_HIP_LIB: diagnostic builds
 
-OK, ERR_BAD_ARG, ERR_HIP, ERR_NAN_IN_TREE, ERR_DEGENERATE_POLICY, ERR_ARENA_OVERFLOW, ERR_NOT_BOUND, ERR_NO_DEVICE, ERR_ILLEGAL_MOVE = range(9)
+OK, ERR_BAD_ARG, ERR_HIP, ERR_NAN_IN_TREE, ERR_DEGENERATE_POLICY, ERR_ARENA_OVERFLOW, ERR_NOT_BOUND, ERR_NO_DEVICE, ERR_ILLEGAL_MOVE, ERR_CANCELLED = range(10)
 STATUS_NAMES = {
     0: "C4_OK", 1: "C4_ERR_BAD_ARG", 2: "C4_ERR_HIP", 3: "C4_ERR_NAN_IN_TREE", 4: "C4_ERR_DEGENERATE_POLICY",
-    5: "C4_ERR_ARENA_OVERFLOW", 6: "C4_ERR_NOT_BOUND", 7: "C4_ERR_NO_DEVICE", 8: "C4_ERR_ILLEGAL_MOVE",
+    5: "C4_ERR_ARENA_OVERFLOW", 6: "C4_ERR_NOT_BOUND", 7: "C4_ERR_NO_DEVICE", 8: "C4_ERR_ILLEGAL_MOVE", 9: "C4_ERR_CANCELLED",
 }
 FLAG_NO_MOVES = 1
 FLAG_ONE_SIM_PER_STEP = 2
 FLAG_RECLAIM = 4          # include/c4a0_hip.h C4_FLAG_RECLAIM: the tree arena is reclaimed while a game is played
 FLAG_NO_RECLAIM = 8       # ... never, also where the default sizing would
 MAX_SAMPLES_PER_GAME = 43
-ABI_VERSION = 9   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
+ABI_VERSION = 10   # include/c4a0_hip.h C4_ABI_VERSION: the signatures below are that version's
 STRUCT_LAYOUT_SINCE = 7   # the ABI version that last changed a structure's layout (c4_config.reclaim_period, c4_counters.reclaim_*)
 
 
@@ -116,6 +116,7 @@ SIGNATURES = {
     "c4_trim_cached_memory": (C.c_int, []),
     "c4_records_to_cbor": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, _P(C.c_uint64)]),
     "c4_shuffle_games": (C.c_int, [C.c_uint64, C.c_uint64, _vp]),
+    "c4_play_games_cancel": (None, []),
     "c4_play_games_bf16": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_float, C.c_float, _P(NetworkBf16), _P(PlayOptions), _vp, _vp, C.c_uint64,
                                      _P(C.c_uint64), _P(Counters), _P(PlayPhases)]),
     "c4_cbor_to_records": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _vp, C.c_uint64, _P(C.c_uint64), _P(C.c_uint64)]),

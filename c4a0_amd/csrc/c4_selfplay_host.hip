@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstddef>
 #include <cstdlib>
@@ -45,6 +46,8 @@ using c4host::fail;
     const int rc_ = (expr);         \
     if (rc_ != C4_OK) return rc_;   \
   } while (0)
+
+std::atomic<uint32_t> g_cancel_requested{0};   // c4_play_games_cancel -> the running job's loop
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -207,6 +210,7 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
   // a host calling at once used to fail that way.  A job fills the device anyway; the second caller waits here.
   static std::mutex one_job;
   std::lock_guard<std::mutex> hold(one_job);
+  g_cancel_requested.store(0, std::memory_order_relaxed);   // a request is for the job that was running when it was made
   const double t0 = now_s();
   c4host::DeviceGuard guard(opt.device);
   if (guard.error() != hipSuccess) return fail(C4_ERR_HIP, std::string("c4_play_games_bf16: hipSetDevice: ") + hipGetErrorString(guard.error()));
@@ -344,6 +348,10 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
     }
     if (started_all && t_all_started == 0.0) { t_all_started = now_s(); steps_all_started = steps; }
     if (done_all) break;
+    if (g_cancel_requested.load(std::memory_order_relaxed)) {
+      (void)j.sync();
+      return fail(C4_ERR_CANCELLED, "c4_play_games_bf16: stopped by c4_play_games_cancel after " + std::to_string(steps) + " rounds");
+    }
     if (since_check >= 64 && started_all) {
       since_check = 0;
       // tail: a session narrows when at most half of its rows still hold a game (decided from the pinned probes: the evaluator is a
@@ -433,3 +441,5 @@ extern "C" int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games
   }
   return C4_OK;
 }
+
+extern "C" void c4_play_games_cancel(void) { g_cancel_requested.store(1, std::memory_order_relaxed); }

@@ -42,6 +42,35 @@ def network_struct(net) -> _lib.NetworkBf16:
     return s
 
 
+def _call_interruptibly(call):
+    """A job is ONE library call -- seconds to minutes in which the interpreter would not see a signal.  The call runs on a helper
+    thread while the caller waits for it (a wait that signals do interrupt): on KeyboardInterrupt (or whatever else arrives) the
+    running job is asked to stop (`c4_play_games_cancel`: it returns after the replays in flight, everything given back), and the
+    exception goes on to the caller, as it would out of the Python loop.  (The status check runs on the helper thread too: the
+    library's error string is per thread.)"""
+    import threading
+
+    box = {}
+
+    def work():
+        try:
+            call()
+        except BaseException as e:  # noqa: BLE001  (handed to the caller below)
+            box["error"] = e
+
+    t = threading.Thread(target=work, name="c4_play_games_bf16", daemon=True)
+    t.start()
+    try:
+        t.join()
+    except BaseException:
+        while t.is_alive():
+            _lib.lib().c4_play_games_cancel()       # (again and again: a request made before the job's loop started is cleared by it)
+            t.join(0.02)
+        raise
+    if "error" in box:
+        raise box["error"]
+
+
 def run_native(ids: np.ndarray, n_mcts_iterations: int, c_exploration: float, c_ply_penalty: float, net, *, resident_games=None,
                concurrent_sessions=None, steps_per_graph: int = 0, tail_steps_per_graph: int = 0, blocks_per_slot: int = 0, reclaim=None,
                reclaim_period: int = 0, dirichlet=None, eval_cache_entries: int = 0, stats: Optional[dict] = None, on_device: bool = False):
@@ -73,8 +102,9 @@ def run_native(ids: np.ndarray, n_mcts_iterations: int, c_exploration: float, c_
         recs_ptr = recs.ctypes.data
     n_recs, totals, phases = C.c_uint64(), _lib.Counters(), _lib.PlayPhases()
     tab = np.ascontiguousarray(ids, dtype=np.uint64)
-    _lib.check(_lib.lib().c4_play_games_bf16(tab.ctypes.data, n, int(n_mcts_iterations), float(c_exploration), float(c_ply_penalty), C.byref(ns),
-                                             C.byref(opt), counts.ctypes.data, recs_ptr, cap, C.byref(n_recs), C.byref(totals), C.byref(phases)))
+    _call_interruptibly(lambda: _lib.check(_lib.lib().c4_play_games_bf16(
+        tab.ctypes.data, n, int(n_mcts_iterations), float(c_exploration), float(c_ply_penalty), C.byref(ns), C.byref(opt), counts.ctypes.data, recs_ptr, cap,
+        C.byref(n_recs), C.byref(totals), C.byref(phases))))
     if stats is not None:
         ph = phases.as_dict()
         stats.update(totals.as_dict())

@@ -24,10 +24,10 @@ extern "C" {
 #endif
 
 /* Version of THIS interface: bumped whenever a signature or a struct layout below changes (version 3 added `config` in the
- * middle of c4_conv_tower_bf16's arguments, version 5 c4_session_step_head_out, version 8 the host-side record codecs c4_records_to_cbor / c4_cbor_to_records / c4_shuffle_games, version 9 c4_play_games_bf16).  A consumer compiled against this header checks it once at start-up --
+ * middle of c4_conv_tower_bf16's arguments, version 5 c4_session_step_head_out, version 8 the host-side record codecs c4_records_to_cbor / c4_cbor_to_records / c4_shuffle_games, version 9 c4_play_games_bf16, version 10 c4_play_games_cancel / C4_ERR_CANCELLED).  A consumer compiled against this header checks it once at start-up --
  * `if (c4_abi_version() != C4_ABI_VERSION) refuse` -- because the dynamic linker compares names, not signatures
  * (tests/abi_consumer*.c and c4a0_amd/_lib.py do).  No reference counterpart: the reference's boundary is PyO3. */
-#define C4_ABI_VERSION 9
+#define C4_ABI_VERSION 10
 
 #define C4_N_COLS 7          /* rust/src/c4r.rs:45, lib.rs:28 */
 #define C4_N_ROWS 6          /* rust/src/c4r.rs:44, lib.rs:29 */
@@ -44,8 +44,9 @@ typedef enum {
   C4_ERR_ARENA_OVERFLOW = 5,    /* blocks_per_slot too small for this game's tree */
   C4_ERR_NOT_BOUND = 6,         /* step before bind_io / set_games */
   C4_ERR_NO_DEVICE = 7,
-  C4_ERR_ILLEGAL_MOVE = 8       /* reference panics: mcts.rs:196-200 (sampled a full column; only possible when the
+  C4_ERR_ILLEGAL_MOVE = 8,      /* reference panics: mcts.rs:196-200 (sampled a full column; only possible when the
                                    root's children have no visits, i.e. n_mcts_iterations <= 1) */
+  C4_ERR_CANCELLED = 9          /* c4_play_games_bf16 stopped by c4_play_games_cancel (the host's Ctrl-C) */
 } c4_status;
 
 /* types.rs:37-48 GameMetadata */
@@ -322,6 +323,11 @@ int c4_play_games_bf16(const c4_game_metadata* reqs, uint64_t n_games, uint32_t 
                        float c_ply_penalty, const c4_network_bf16* net, const c4_play_options* options, uint32_t* counts_host,
                        c4_sample_rec* records_host, uint64_t records_cap, uint64_t* n_records, c4_counters* totals,
                        c4_play_phases* phases);
+/* Asks the c4_play_games_bf16 call that is running (on whatever thread) to stop: it returns C4_ERR_CANCELLED after the graph replays
+ * in flight (milliseconds), with everything given back and no records.  For a host's interrupt handling -- the reference's job is
+ * stopped by killing the process; a job here can be minutes of one library call.  Has no effect when no job is running (a job
+ * clears the request when it starts), and none on the c4_session_* entry points.  Callable from any thread. */
+void c4_play_games_cancel(void);
 
 /* ---- the hand-off right after the path: PlayGamesResult's wire format on the packed records (HOST functions: no device is
  * touched, they work on a machine without a GPU). ----

@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     from c4a0_amd import _lib
 
     hdr = open(os.path.join(ROOT, "include", "c4a0_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(c4_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(c4_\w+)\s*\(", hdr, flags=re.M))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     L = _lib.lib()
     for name in declared:
