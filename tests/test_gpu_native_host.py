@@ -236,7 +236,8 @@ def test_a_device_side_panic_ends_the_call_and_poisons_nothing(sessions):
     assert play_games_native(reqs, 4096, 8, 6.6, 0.01, good, **kw).to_records()[0].tobytes() == want
 
 
-def test_ctrl_c_stops_a_job_inside_the_library():
+@pytest.mark.parametrize("host_loop", ["native", "python"])
+def test_ctrl_c_stops_a_job_inside_the_library(host_loop):
     """The whole job is one library call; SIGINT during it must still reach the caller promptly (the Python loop is interruptible
     between replays, the reference's process is simply killed): the call runs on a helper thread, the interrupted caller asks the
     job to stop (`c4_play_games_cancel` -> C4_ERR_CANCELLED inside, KeyboardInterrupt outside), everything is given back and the
@@ -254,16 +255,18 @@ def test_ctrl_c_stops_a_job_inside_the_library():
     want = c4a0_amd.play_games(small, 4096, 10, 6.6, 0.01, evaluator=net).to_records()[0].tobytes()
     torch.cuda.synchronize()
     lib().c4_trim_cached_memory()                                           # (arenas are kept between calls: INTEGRATION.md "Memory between calls")
+    torch.cuda.empty_cache()                                                # (and so are the Python loop's activation buffers, by torch's allocator)
     free_before = torch.cuda.mem_get_info()[0]
     big = [c4a0_amd.GameMetadata(g, 0, 0) for g in range(200000)]           # ~ 7 s of play if left alone
     threading.Timer(0.5, lambda: os.kill(os.getpid(), signal.SIGINT)).start()
     t0 = time.perf_counter()
-    with pytest.raises(KeyboardInterrupt):
-        c4a0_amd.play_games(big, 4096, 100, 6.6, 0.01, evaluator=net)
+    with pytest.raises(KeyboardInterrupt):     # ("python": the loop of session.py, interruptible between replays -- it must give everything back too)
+        c4a0_amd.play_games(big, 4096, 100, 6.6, 0.01, evaluator=net, host_loop=host_loop)
     assert time.perf_counter() - t0 < 3.0
     assert ERR_CANCELLED == 9
     lib().c4_play_games_cancel()                                            # with no job running: no effect on the next one
     assert c4a0_amd.play_games(small, 4096, 10, 6.6, 0.01, evaluator=net).to_records()[0].tobytes() == want
     torch.cuda.synchronize()
     lib().c4_trim_cached_memory()
+    torch.cuda.empty_cache()
     assert free_before - torch.cuda.mem_get_info()[0] < 8 << 20
