@@ -1357,6 +1357,10 @@ using c4host::fail;
 
 int c4host::fail(int code, const std::string& msg) {
   g_last_error = msg;
+  // HIP keeps a failed call's code as the thread's "last error" until somebody reads it; the launch checks of this library read it
+  // (hipGetLastError after every launch), so a failed hipMalloc of ONE call -- device memory full -- used to surface as "out of
+  // memory" in the next call's first launch, long after the memory was there again.  The failure is reported here: take it off.
+  if (code == C4_ERR_HIP) (void)hipGetLastError();
   return code;
 }
 

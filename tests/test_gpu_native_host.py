@@ -270,3 +270,28 @@ def test_ctrl_c_stops_a_job_inside_the_library(host_loop):
     lib().c4_trim_cached_memory()
     torch.cuda.empty_cache()
     assert free_before - torch.cuda.mem_get_info()[0] < 8 << 20
+
+
+@pytest.mark.parametrize("host_loop", ["native", "python"])
+def test_a_job_that_does_not_fit_fails_cleanly(host_loop):
+    """Device memory nearly full (somebody else's tensors): the job's arenas cannot be allocated -- the call must say so, keep
+    nothing, and the same job must run once the memory is there."""
+    import c4a0_amd
+    from c4a0_amd._lib import C4Error, lib
+
+    net = _net(1, 32)
+    reqs = [c4a0_amd.GameMetadata(g, 0, 0) for g in range(2048)]
+    lib().c4_trim_cached_memory()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    free = torch.cuda.mem_get_info()[0]
+    hog = torch.empty(free - (1 << 30), dtype=torch.uint8, device="cuda:0")       # leaves 1 GB; the job below wants 2 048 x 43 x 900 x 128 B = 10 GB
+    with pytest.raises((C4Error, RuntimeError, MemoryError)):
+        c4a0_amd.play_games(reqs, 4096, 900, 6.6, 0.01, evaluator=net, host_loop=host_loop)
+    torch.cuda.synchronize()
+    lib().c4_trim_cached_memory()
+    assert torch.cuda.mem_get_info()[0] > (1 << 30) - (64 << 20)                   # what the failed call took is back
+    del hog
+    torch.cuda.empty_cache()
+    small = c4a0_amd.play_games(reqs[:200], 4096, 12, 6.6, 0.01, evaluator=net, host_loop=host_loop)
+    assert len(small.results) == 200 and all(len(r.samples) >= 7 for r in small.results)
