@@ -561,3 +561,55 @@ def test_arena_is_kept_for_the_next_session_and_can_be_trimmed():
     arena = 32 * (43 * 60 + 8) * 128                      # the biggest of the four
     assert free2 - free1 >= arena // 2 and free0 - free1 >= arena // 2, (free0, free1, free2, arena)
     c4a0_amd.trim_cached_memory()                          # nothing kept: still fine
+
+
+def test_an_evaluator_that_fails_mid_job_poisons_nothing():
+    """The caller's evaluator raises in the middle of a job -- a numpy callback, a device callable launched eagerly, a graph-safe one
+    (which may be inside a HIP-graph capture at that moment): the exception reaches the caller (the reference panics,
+    pybridge.rs:182-183), the sessions are closed, and the next job returns the bytes it always returns."""
+    import c4a0_amd
+    from c4a0_amd._lib import lib
+    from tests.helpers import hash_eval_np, hash_eval_torch
+
+    reqs = [c4a0_amd.GameMetadata(g, 0, 0) for g in range(300)]
+    want = c4a0_amd.play_games(reqs, 64, 12, 6.6, 0.01, hash_eval_np).to_records()[0].tobytes()
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        lib().c4_trim_cached_memory()
+        torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info()[0]
+
+    calls = {"np": 0, "graph": 0, "eager": 0}
+
+    def np_cb(model_id, pos):
+        calls["np"] += 1
+        if calls["np"] == 7:
+            raise RuntimeError("boom (numpy callback)")
+        return hash_eval_np(model_id, pos)
+
+    def graph_safe(planes, out_logprobs=None, out_q=None):
+        calls["graph"] += 1
+        if calls["graph"] == 5:
+            raise RuntimeError("boom (graph-safe device callable)")
+        lp, q = hash_eval_torch(planes)
+        out_logprobs.copy_(lp)
+        out_q.copy_(q)
+
+    graph_safe.graph_safe = True
+
+    def eager(planes):
+        calls["eager"] += 1
+        if calls["eager"] == 40:
+            raise RuntimeError("boom (eager device callable)")
+        return hash_eval_torch(planes)
+
+    free0 = None
+    for kw in (dict(py_eval_pos_cb=np_cb), dict(evaluator=graph_safe), dict(evaluator=eager)):
+        with pytest.raises(RuntimeError, match="boom"):
+            c4a0_amd.play_games(reqs, 64, 12, 6.6, 0.01, **kw)
+        again = c4a0_amd.play_games(reqs, 64, 12, 6.6, 0.01, evaluator=hash_eval_torch).to_records()[0].tobytes()
+        assert again == want, kw
+        if free0 is None:
+            free0 = free_bytes()                       # (after the first failure: one-time pools of torch's graph allocator are in)
+    assert free0 - free_bytes() < 128 << 20
